@@ -1,0 +1,221 @@
+/*
+ * rrt.h -- C ABI of librrt_hip.so, the MI355X (gfx950) path-tracing core.
+ *
+ * The reference program has no FFI; its integrator is entered through one Rust
+ * call, renderer::render(scene, settings, sampler, camera) (src/renderer.rs:92-97,
+ * called from src/main.rs:315).  The entry points below are what a Rust `ffi.rs`
+ * for that seam binds: the scene the loader built (src/scene.rs:55-207) goes
+ * down once as flat arrays, the camera as the two matrices Camera::new derives
+ * (src/camera.rs:39-101), and each call of rrt_render does the work of
+ * render_work + trace (src/renderer.rs:184-211, src/tracer.rs:24-139) for a
+ * range of sample indices, accumulating the per-pixel sums that
+ * Film::write_bucket_pixels / merge_bucket_pixels_to_image_buffer keep
+ * (src/film.rs:150-251).
+ *
+ * Conventions: every function returns 0 on success or a negative RRT_E_* code
+ * and never throws or aborts across the boundary; all pointers are caller
+ * owned and only read during the call unless stated; a context is driven by
+ * one host thread at a time, different contexts may be driven concurrently.
+ */
+#ifndef RRT_H
+#define RRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRT_OK 0
+#define RRT_E_INVALID (-1)  /* bad argument (null pointer, zero size, bad enum) */
+#define RRT_E_DEVICE (-2)   /* a HIP call failed; see rrt_last_error */
+#define RRT_E_STATE (-3)    /* call order: no scene / no camera / no film */
+#define RRT_E_NOMEM (-4)    /* host or device allocation failed */
+#define RRT_E_UNSUPPORTED (-5)
+
+typedef struct rrt_ctx rrt_ctx;
+
+/* Material kinds: src/materials.rs:14-20. */
+enum { RRT_MAT_MATTE = 0, RRT_MAT_PLASTIC = 1, RRT_MAT_MIRROR = 2, RRT_MAT_GLASS = 3 };
+
+/* One material.  Field use per kind (constructor argument order of the reference):
+ *   MATTE   (materials/matte.rs:17-23):   kd = reflectance, roughness = sigma (raw value)
+ *   PLASTIC (materials/plastic.rs:24-33): kd = diffuse, ks = specular, roughness, ior
+ *   MIRROR  (materials/mirror.rs:14-17):  kd = reflectance
+ *   GLASS   (materials/glass.rs:17-29):   ior, kd = reflection colour, ks = refraction colour */
+typedef struct rrt_material {
+  uint32_t kind;
+  uint32_t _pad;
+  double kd[3];
+  double ks[3];
+  double roughness;
+  double ior;
+} rrt_material;
+
+/* Light kinds: src/lights.rs:15-21. */
+enum { RRT_LIGHT_POINT = 0, RRT_LIGHT_AREA = 1, RRT_LIGHT_DISTANT = 2, RRT_LIGHT_INFINITE = 3 };
+
+/* One light, in scene.lights order (src/scene.rs:72-132: yaml order, the
+ * environment light last).
+ *   POINT    (lights/point.rs:66-72):   v0 = position
+ *   AREA     (lights/area.rs:66-69 over a Rectangle): v0 = position, v1 = side_a, v2 = side_b
+ *   DISTANT  (lights/distant.rs:71-84): v0 = direction towards the light (normalised by the library)
+ *   INFINITE (lights/infinite_area.rs:113-139): texels come from env_rgb8; intensity unused */
+typedef struct rrt_light {
+  uint32_t kind;
+  uint32_t _pad;
+  double intensity[3];
+  double v0[3];
+  double v1[3];
+  double v2[3];
+} rrt_light;
+
+/* Rectangle (src/objects/rectangle.rs:17-24). light = index into lights[] of
+ * the area light this quad belongs to, or -1. */
+typedef struct rrt_rect {
+  double pos[3];
+  double side_a[3];
+  double side_b[3];
+  uint32_t material;
+  int32_t light;
+} rrt_rect;
+
+/* Plane (src/objects/plane.rs:18-23). */
+typedef struct rrt_plane {
+  double pos[3];
+  double normal[3];
+  uint32_t material;
+  uint32_t _pad;
+} rrt_plane;
+
+/* Sphere (src/objects/sphere.rs:15-20). */
+typedef struct rrt_sphere {
+  double center[3];
+  double radius;
+  uint32_t material;
+  uint32_t _pad;
+} rrt_sphere;
+
+/* How the reference's f32 bounding-box pre-filter (bvh crate, leaf AABB of
+ * each shape, src/objects/rectangle.rs:136-146) treats quads whose box is flat:
+ * STRICT = slab test tmax > max(tmin, 0): a zero-thickness box is never hit;
+ * INCLUSIVE = tmax >= max(tmin, 0); OFF = no pre-filter. */
+enum { RRT_RECT_AABB_STRICT = 0, RRT_RECT_AABB_INCLUSIVE = 1, RRT_RECT_AABB_OFF = 2 };
+
+/* The flattened scene.  Object ids (as reported by rrt_intersect) follow the
+ * order of Scene.objects (src/scene.rs:64-106, 315-325): triangles in OBJ
+ * model / face / fan order, then rectangles, then planes, then spheres. */
+typedef struct rrt_scene_desc {
+  uint32_t n_tris;
+  uint32_t n_rects;
+  uint32_t n_planes;
+  uint32_t n_spheres;
+  uint32_t n_materials;
+  uint32_t n_lights;
+  const float* tri_pos;     /* [n_tris][3 vertices][xyz], f32 as in the OBJ (objects/triangle.rs:59-82) */
+  const float* tri_nrm;     /* [n_tris][3 vertices][xyz] vertex normals (objects/triangle.rs:84-107) */
+  const uint32_t* tri_mat;  /* [n_tris] material index */
+  const rrt_rect* rects;
+  const rrt_plane* planes;
+  const rrt_sphere* spheres;
+  const rrt_material* materials;
+  const rrt_light* lights;
+  const uint8_t* env_rgb8;  /* [env_h][env_w][3] texels as InfiniteAreaLight::new stores them; may be null */
+  uint32_t env_w;
+  uint32_t env_h;
+  uint32_t rect_aabb_mode;  /* RRT_RECT_AABB_* */
+  uint32_t _pad;
+} rrt_scene_desc;
+
+/* Settings (src/renderer.rs:24-30) plus the film geometry the integrator needs
+ * (src/film.rs:67-74, crop: src/main.rs:263-275).  Pixels outside
+ * [crop_x0,crop_x1) x [crop_y0,crop_y1) are not rendered. */
+typedef struct rrt_settings {
+  uint32_t width;
+  uint32_t height;
+  uint32_t crop_x0, crop_y0, crop_x1, crop_y1;
+  uint32_t depth_limit;
+  uint32_t _pad;
+  double clamp;   /* <= 0: no clamp (src/tracer.rs:116) */
+  uint64_t seed;  /* counter-based RNG seed; replaces the Sobol / thread RNG of src/sampler.rs */
+} rrt_settings;
+
+typedef struct rrt_stats {
+  uint64_t paths;            /* camera paths started */
+  uint64_t rays_extend;      /* closest-hit queries (src/renderer.rs:213) */
+  uint64_t rays_shadow;      /* any-hit queries (src/renderer.rs:251) incl. MIS escape rays */
+  uint64_t path_bounces;     /* surface interactions shaded */
+  double ms_raygen, ms_extend, ms_shade, ms_connect, ms_film; /* kernel time, valid when timing is on */
+  uint64_t launches_extend;  /* extend launches the times above cover */
+  uint64_t bvh_nodes;
+  uint64_t bvh_bytes;        /* node + triangle bytes resident on the device */
+} rrt_stats;
+
+/* Number of visible HIP devices, or a negative code. */
+int rrt_device_count(void);
+
+/* Creates a context on `device`; null on failure (rrt_last_error(NULL) explains). */
+rrt_ctx* rrt_create(int device);
+void rrt_destroy(rrt_ctx* ctx);
+
+/* Launch all later work on this hipStream_t (null = the default stream). */
+int rrt_set_stream(rrt_ctx* ctx, void* hip_stream);
+
+/* Copies the scene, builds the BVH and uploads both.  Replaces Arc<Scene> +
+ * Bvh::build (src/scene.rs:196, src/renderer.rs:98). */
+int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* scene);
+
+/* Camera::new's raster_to_camera and camera_to_world (row-major 4x4,
+ * src/camera.rs:60-88), aperture and focal_distance (src/camera.rs:103-125). */
+int rrt_set_camera(rrt_ctx* ctx, const double raster_to_camera[16], const double camera_to_world[16],
+                   double aperture, double focal_distance);
+
+/* Film accumulator: float [height][width][4] = (sum_r, sum_g, sum_b, sum_weight)
+ * per pixel (Pixel.sum_radiance / sum_weight, src/film.rs:46-52), resident on
+ * the device.  rrt_film_alloc makes the library own one (zeroed);
+ * rrt_film_bind makes it use caller-owned device memory instead (not zeroed). */
+int rrt_film_alloc(rrt_ctx* ctx, uint32_t width, uint32_t height);
+int rrt_film_bind(rrt_ctx* ctx, float* device_ptr, uint32_t width, uint32_t height);
+int rrt_film_clear(rrt_ctx* ctx);
+int rrt_film_download(rrt_ctx* ctx, float* host_sum_rgbw);
+void* rrt_film_device_ptr(rrt_ctx* ctx);
+
+/* Renders sample indices [sample_begin, sample_end) of every pixel in the crop
+ * window and adds them to the film: the pixel x max_samples loop of render_work
+ * (src/renderer.rs:191-207) with trace (src/tracer.rs:24) inside.  Returns when
+ * the work has been enqueued on the context's stream; rrt_synchronize waits. */
+int rrt_render(rrt_ctx* ctx, const rrt_settings* settings, uint32_t sample_begin, uint32_t sample_end);
+int rrt_synchronize(rrt_ctx* ctx);
+
+/* Sums the film accumulators of n contexts (one per GPU, one process) into
+ * ctxs[root] with RCCL.  Multi-process callers reduce the bound film buffer
+ * with their own communicator instead. */
+int rrt_film_reduce(rrt_ctx** ctxs, int n, int root);
+
+/* check_intersect_scene (src/renderer.rs:213-249) for n rays given as host
+ * [n][6] = origin xyz, direction xyz: object id of the closest hit (-1 = miss)
+ * and its distance. */
+int rrt_intersect(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_t* prim_id, float* t);
+
+/* check_intersect_scene_simple (src/renderer.rs:251-275) for n rays given as
+ * host [n][7] = origin, direction, max_dist: 1 if anything is hit closer than
+ * max_dist. */
+int rrt_occluded(rrt_ctx* ctx, const float* org_dir_tmax, uint32_t n, uint8_t* hit);
+
+/* Options. */
+enum {
+  RRT_OPT_TIMING = 1,        /* 1: time each kernel with HIP events (serialises batches) */
+  RRT_OPT_BATCH_SAMPLES = 2  /* samples per pixel kept in flight per batch (0 = automatic) */
+};
+int rrt_set_option(rrt_ctx* ctx, int option, int64_t value);
+
+int rrt_get_stats(rrt_ctx* ctx, rrt_stats* out);
+int rrt_reset_stats(rrt_ctx* ctx);
+
+/* Last error text of this context (or of rrt_create when ctx is null). */
+const char* rrt_last_error(rrt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRT_H */

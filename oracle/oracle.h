@@ -1,0 +1,103 @@
+/*
+ * oracle.h -- C interface of the CPU oracle (liboracle.so).
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a double-precision CPU restatement of the
+ * reference's integrator (src/tracer.rs, src/renderer.rs and everything they
+ * call), used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg as the checker and the timed CPU baseline.  Nothing in the product
+ * (rust-raytracer_amd/) includes, links or calls it.
+ *
+ * Pinning: the reference is Rust and cannot be built here (no cargo/rustc, 15
+ * crates not vendored), so the oracle is pinned only by the known-answer tests
+ * the reference's own #[cfg(test)] modules hold (tests/test_oracle_kat.py lists
+ * them with file:line).  Those cover the triangle test, Fresnel, specular
+ * reflection, GGX sampling sanity, helpers and the camera.  Nothing in the
+ * reference pins trace / estimate_direct, closest-hit selection, lights, film
+ * or any image: for those, parity is UNPINNED beyond this restatement's reading
+ * of the source.  The bvh 0.8.0 crate (candidate filter) and tobj 3.2.5 are not
+ * in the snapshot; their behaviour is restated from their published algorithms.
+ *
+ * It takes the same flattened scene (rrt_scene_desc), camera matrices and
+ * settings as the device library and draws the same counter-based random
+ * numbers, so a device render and an oracle render of the same (pixel, sample)
+ * follow the same path up to float-vs-double rounding.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include <stdint.h>
+
+#include "../include/rrt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_ctx orc_ctx;
+
+typedef struct orc_stats {
+  uint64_t paths;
+  uint64_t rays_extend;      /* check_intersect_scene calls */
+  uint64_t rays_shadow;      /* check_intersect_scene_simple calls */
+  uint64_t path_bounces;
+  uint64_t nodes_visited;    /* BVH boxes tested */
+  uint64_t prims_tested;     /* exact shape tests */
+  double seconds;            /* wall clock around the bucket loop (src/renderer.rs:121-166) */
+  uint32_t threads;
+} orc_stats;
+
+orc_ctx* orc_create(const rrt_scene_desc* scene);
+void orc_destroy(orc_ctx* ctx);
+int orc_set_camera(orc_ctx* ctx, const double raster_to_camera[16], const double camera_to_world[16],
+                   double aperture, double focal_distance);
+
+/* render + render_work + trace + Film (src/renderer.rs:92-211, src/film.rs:150-251):
+ * `threads` workers pull bucket_w x bucket_h buckets from a mutex-guarded queue;
+ * film_sum_rgbw is double [height][width][4], added to. */
+int orc_render(orc_ctx* ctx, const rrt_settings* settings, uint32_t sample_begin, uint32_t sample_end,
+               uint32_t bucket_w, uint32_t bucket_h, uint32_t threads, double* film_sum_rgbw, orc_stats* stats);
+
+/* trace() for one (pixel, sample): radiance out[3]. */
+int orc_trace_one(orc_ctx* ctx, const rrt_settings* settings, uint32_t px, uint32_t py, uint32_t sample,
+                  double out[3]);
+
+/* check_intersect_scene / check_intersect_scene_simple on explicit rays. */
+int orc_intersect(orc_ctx* ctx, const double* org_dir, uint32_t n, int32_t* prim_id, double* t);
+int orc_occluded(orc_ctx* ctx, const double* org_dir_tmax, uint32_t n, uint8_t* hit);
+/* As orc_intersect, plus how well separated the winner is, so that tests can
+ * set aside rays whose answer legitimately depends on rounding:
+ * margin[i] = min over {barycentrics of the hit, |d.ng|, relative gap to the
+ * second-closest candidate}. */
+int orc_intersect_margin(orc_ctx* ctx, const double* org_dir, uint32_t n, int32_t* prim_id, double* t,
+                         double* margin);
+
+/* The random number stream both implementations draw from. */
+double orc_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t block, uint32_t index);
+
+/* ---- single functions, exposed for the reference's known-answer tests ---- */
+/* Triangle::test_intersect (src/objects/triangle.rs:119-257): returns 1 on hit. */
+int orc_triangle_intersect(const double p[9], const double n[9], const double org[3], const double dir[3],
+                           double* t, double point[3], double shading_normal[3], double geometry_normal[3]);
+double orc_fresnel_dielectric(double eta_i, double eta_t, double cos_theta_i); /* bsdf/helpers/fresnel.rs:47-74 */
+double orc_get_fresnel_ratio(const double normal[3], const double incidence[3], double ior); /* helpers.rs:97-128 */
+int orc_max_dimension(const double v[3]);                                      /* helpers.rs:182-194 */
+void orc_permute(const double v[3], int x, int y, int z, double out[3]);       /* helpers.rs:196-198 */
+double orc_spherical_phi(const double v[3]);                                   /* helpers.rs:230-238 */
+double orc_spherical_theta(const double v[3]);                                 /* helpers.rs:226-228 */
+void orc_tr_sample_11(double cos_theta, double u1, double u2, double out[2]);  /* microfacet_distribution.rs:56-103 */
+void orc_tr_sample(const double wi[3], double ax, double ay, double u1, double u2, double out[3]); /* :105-123 */
+void orc_tr_sample_wh(const double wo[3], double ax, double ay, int visible, double u1, double u2, double out[3]);
+double orc_tr_pdf(const double wo[3], const double wh[3], double ax, double ay, int visible); /* :31-37 */
+/* MicrofacetReflection::f (bsdf/microfacet_reflection.rs:41-60), Dielectric(eta_i, eta_t) */
+void orc_microfacet_f(const double r[3], double ax, double ay, double eta_i, double eta_t, const double wo[3],
+                      const double wi[3], double out[3]);
+/* SpecularReflection::sample_f / f / pdf (bsdf/specular_reflection.rs:22-42); fresnel_kind 0 = Noop, 1 = Dielectric */
+void orc_specular_reflection_sample_f(const double r[3], int fresnel_kind, double eta_i, double eta_t,
+                                      const double wo[3], double wi[3], double* pdf, double f[3]);
+/* Film tone map of one pixel (src/film.rs:236-247). */
+void orc_tonemap_pixel(const double radiance[3], uint8_t rgb[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
