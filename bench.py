@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: camera-path samples/s of the path-tracing hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+scene/buddha at 1920x1080, 256 samples per pixel, depth 12, clamp 10, aperture 0.1, the scene's
+three area lights + distant light + environment map with MIS, a ~1.09 M-triangle mesh with the
+microfacet plastic material (Kd .6 / Ks 1 / Pr 0.27 / Ni 1.5).  The Happy Buddha OBJ is not part of
+the reference snapshot, so a generated stand-in of the same triangle count is used unless
+scenes/buddha/happy-buddha.obj exists.  Synthetic data, no files are read from the reference.
+
+One step = one pass of the hot path over the whole frame: rrt_render of 256 samples of every pixel
+(raygen, then extend / shade / connect per bounce, then film accumulation), scene and film resident
+in HBM before the clock starts.  With N GPUs (launched by torch.distributed.run, one rank per GPU)
+rank r renders sample indices [256 r, 256 (r+1)) and the per-GPU films are summed onto rank 0 with
+one RCCL reduce inside the timed region: weak scaling, value = all ranks' camera paths / max time.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+"""
+import argparse
+import ctypes
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def _load(name, rel):
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(ROOT, rel)
+    kw = {"submodule_search_locations": [os.path.dirname(path)]} if rel.endswith("__init__.py") else {}
+    spec = importlib.util.spec_from_file_location(name, path, **kw)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+rr = _load("rust_raytracer_amd", "rust-raytracer_amd/__init__.py")
+standin = _load("rust_raytracer_amd.standin", "rust-raytracer_amd/standin.py")
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+# algorithmic bytes per ray: 64 B per BVH node visited (two child boxes + links), 36 B per triangle
+# tested (nine f32 positions), 32 B ray in, 16 B hit out
+NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 64, 36, 32, 16
+
+
+def load_buddha(width, height):
+    folder = os.path.join(rr.SCENES, "buddha")
+    rs = rr.load_render_settings(folder)
+    # the "microfacet" configuration: Plastic -> Lambertian + Trowbridge-Reitz with alpha = 0.27^2
+    material = rr.make_material(rr.MAT_PLASTIC, kd=(0.6, 0.6, 0.6), ks=(1.0, 1.0, 1.0), roughness=0.27, ior=1.5)
+    if os.path.exists(os.path.join(folder, "happy-buddha.obj")):
+        scene = rr.Scene.load_from_folder(folder)
+        scene.set_material(0, material)
+        mesh = "happy-buddha.obj"
+    else:
+        pos, nrm = standin.happy_buddha_standin()
+        scene = rr.Scene.load_from_folder_with_mesh(folder, pos, nrm, material)
+        mesh = "generated stand-in"
+    camera = rr.Camera.from_settings(rs, width, height)
+    return scene, rs, camera, mesh
+
+
+def cpu_baseline(scene, rs, threads, budget_paths):
+    """Times the CPU oracle (port of the reference algorithm) on a bounded sample of the same workload:
+    the same scene, camera, depth and clamp at 1/12 of the resolution in each direction."""
+    from oracle import binding as ob
+    w, h = 160, 90
+    spp = max(1, budget_paths // (w * h))
+    cam = rr.Camera.from_settings(rs, w, h)
+    orc = ob.Oracle(scene.desc())
+    orc.set_camera(cam)
+    s = rr.make_settings(w, h, rs.depth_limit, rs.clamp, seed=0)
+    _, st = orc.render(s, 0, spp, threads=threads)
+    rays = st.rays_extend + st.rays_shadow
+    return {
+        "value": st.paths / st.seconds,
+        "unit": "samples/s",
+        "cores": int(st.threads),
+        "kind": "port",
+        "sample": "same scene/camera/depth at %dx%d, %d spp (%d camera paths), %.1f s" % (w, h, spp, st.paths, st.seconds),
+        "mrays_per_s": rays / st.seconds * 1e-6,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--cpu-paths", type=int, default=120000, help="camera paths of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--batch-samples", type=int, default=0)
+    ap.add_argument("--no-calibrate", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" %
+                             (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    W, H, SPP = args.width, args.height, args.spp
+    scene, rs, camera, mesh = load_buddha(W, H)
+    ctx = rr.Context(local_rank)
+    ctx.upload_scene(scene)
+    ctx.set_camera(camera)
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
+    ctx.film_bind(film.data_ptr(), W, H)
+    stream = torch.cuda.current_stream(device)
+    ctx.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    if args.batch_samples:
+        ctx.set_option(rr.OPT_BATCH_SAMPLES, args.batch_samples)
+    settings = rr.make_settings(W, H, rs.depth_limit, rs.clamp, seed=0)
+    s_begin, s_end = rank * SPP, (rank + 1) * SPP
+
+    def step():
+        film.zero_()
+        ctx.render(settings, s_begin, s_end)
+        if dist is not None:
+            dist.reduce(film, dst=0)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # ---- calibration (untimed): nodes / triangles fetched per ray, for the roofline's algorithmic bytes
+    per_ray = None
+    if rank == 0 and not args.no_calibrate:
+        ctx.set_option(rr.OPT_COUNT_TRAVERSAL, 1)
+        ctx.reset_stats()
+        film.zero_()
+        ctx.render(settings, s_begin, s_begin + 2)
+        st = ctx.stats()
+        rays = st.rays_extend + st.rays_shadow
+        per_ray = (st.nodes_visited / rays, st.tris_tested / rays)
+        ctx.set_option(rr.OPT_COUNT_TRAVERSAL, 0)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.set_option(rr.OPT_TIMING, 1)
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = ctx.stats()
+    ctx.set_option(rr.OPT_TIMING, 0)
+
+    paths_all = float(W) * H * SPP * args.steps * world
+    value = paths_all / elapsed
+    rays_rank = st.rays_extend + st.rays_shadow
+    out = None
+    if rank == 0:
+        # sanity: the film holds `world` x SPP samples per pixel and finite radiance
+        fsum = film.sum(dim=(0, 1)).tolist()
+        assert abs(fsum[3] - float(W) * H * SPP * world) < 1e-3 * W * H * SPP * world, fsum
+        assert all(x == x and x > 0 for x in fsum[:3]), fsum
+        roofline = None
+        if per_ray is not None and st.launches_extend:
+            bytes_per_ray = per_ray[0] * NODE_BYTES + per_ray[1] * TRI_BYTES + RAY_BYTES + HIT_BYTES
+            launch_bytes = st.rays_extend * bytes_per_ray / st.launches_extend
+            launch_s = st.ms_extend * 1e-3 / st.launches_extend
+            achieved = launch_bytes / launch_s * 1e-9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            roofline = {"kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "bytes_per_ray": bytes_per_ray, "nodes_per_ray": per_ray[0], "tris_per_ray": per_ray[1],
+                        "launches": int(st.launches_extend), "avg_launch_ms": st.ms_extend / st.launches_extend}
+        out = {
+            "metric": "camera-path samples/sec",
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "scene/buddha %dx%d, %d spp per GPU, depth %d, clamp %g, aperture %g, "
+                                   "microfacet plastic, 3 area + distant + environment lights with MIS" %
+                                   (W, H, SPP, rs.depth_limit, rs.clamp, rs.aperture),
+                       "mesh": mesh, "triangles": int(scene.desc().n_tris), "sharding": "sample index ranges per GPU"},
+            "mrays_per_s": rays_rank * world / elapsed * 1e-6,
+            "rays_per_path": rays_rank / float(st.paths) if st.paths else None,
+            "bounces_per_path": st.path_bounces / float(st.paths) if st.paths else None,
+            "kernel_ms_per_step": {"raygen": st.ms_raygen / args.steps, "extend": st.ms_extend / args.steps,
+                                   "shade": st.ms_shade / args.steps, "connect": st.ms_connect / args.steps,
+                                   "film": st.ms_film / args.steps},
+            "roofline": roofline,
+        }
+        if world == 1 and args.cpu_paths > 0:
+            out["cpu_baseline"] = cpu_baseline(scene, rs, args.cpu_threads, args.cpu_paths)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

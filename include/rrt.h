@@ -147,6 +147,8 @@ typedef struct rrt_stats {
   uint64_t path_bounces;     /* surface interactions shaded */
   double ms_raygen, ms_extend, ms_shade, ms_connect, ms_film; /* kernel time, valid when timing is on */
   uint64_t launches_extend;  /* extend launches the times above cover */
+  uint64_t nodes_visited;    /* BVH nodes fetched, counted only while RRT_OPT_COUNT_TRAVERSAL is on */
+  uint64_t tris_tested;      /* triangle records fetched, counted likewise */
   uint64_t bvh_nodes;
   uint64_t bvh_bytes;        /* node + triangle bytes resident on the device */
 } rrt_stats;
@@ -204,8 +206,10 @@ int rrt_occluded(rrt_ctx* ctx, const float* org_dir_tmax, uint32_t n, uint8_t* h
 
 /* Options. */
 enum {
-  RRT_OPT_TIMING = 1,        /* 1: time each kernel with HIP events (serialises batches) */
-  RRT_OPT_BATCH_SAMPLES = 2  /* samples per pixel kept in flight per batch (0 = automatic) */
+  RRT_OPT_TIMING = 1,          /* 1: time each kernel with HIP events (the host waits at the end of every batch) */
+  RRT_OPT_BATCH_SAMPLES = 2,   /* samples per pixel kept in flight per batch (0 = automatic) */
+  RRT_OPT_MAX_SLOTS = 3,       /* upper bound on paths in flight per batch (sizes the path-state arrays) */
+  RRT_OPT_COUNT_TRAVERSAL = 4  /* 1: count nodes_visited / tris_tested (slower kernels; for calibration runs) */
 };
 int rrt_set_option(rrt_ctx* ctx, int option, int64_t value);
 

@@ -1,0 +1,284 @@
+// Host-side BVH builder for the device traversal kernels.
+//
+// The reference builds its hierarchy with bvh 0.8.0 (`Bvh::build(&mut objects)`,
+// src/scene.rs:196) and only ever uses it as a conservative candidate filter
+// (src/renderer.rs:226-246): the closest hit is the minimum over exact tests,
+// so any correct hierarchy over the same triangles gives the same answer.
+// This one is built for the GPU: binned SAH (16 bins, all three axes), leaves
+// of up to 4 triangles stored contiguously, two child boxes per 64-byte node,
+// nodes laid out in depth-first order, subtrees built on separate threads.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "rrt_device.h"
+
+namespace rrt {
+
+namespace {
+
+struct Box {
+  float mn[3], mx[3];
+  void reset() {
+    for (int k = 0; k < 3; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
+  }
+  void grow(const float* lo, const float* hi) {
+    for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], lo[k]); mx[k] = std::max(mx[k], hi[k]); }
+  }
+  void grow(const Box& b) { grow(b.mn, b.mx); }
+  void grow_point(const float* p) { grow(p, p); }
+  float half_area() const {
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    if (!(dx >= 0.0f)) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+constexpr int kBins = 16;
+constexpr uint32_t kMaxLeaf = 4;
+constexpr uint32_t kSahDepthLimit = 40;     // below this depth splits fall back to the object median
+constexpr uint32_t kSpawnThreshold = 1u << 16;
+
+struct Builder {
+  const float* pos;
+  uint32_t n;
+  std::vector<float> tmin, tmax, cent;  // [n][3]
+  uint32_t* idx;
+  BvhNode* nodes;
+  std::atomic<uint32_t> node_count{0};
+  std::atomic<int> free_threads{0};
+  std::atomic<uint32_t> max_depth{0};
+
+  void prepare() {
+    tmin.resize((size_t)n * 3);
+    tmax.resize((size_t)n * 3);
+    cent.resize((size_t)n * 3);
+    for (uint32_t i = 0; i < n; ++i) {
+      const float* p = pos + (size_t)i * 9;
+      for (int k = 0; k < 3; ++k) {
+        const float lo = std::min(p[k], std::min(p[3 + k], p[6 + k]));
+        const float hi = std::max(p[k], std::max(p[3 + k], p[6 + k]));
+        tmin[(size_t)i * 3 + k] = lo;
+        tmax[(size_t)i * 3 + k] = hi;
+        cent[(size_t)i * 3 + k] = 0.5f * lo + 0.5f * hi;
+      }
+    }
+  }
+
+  // Builds the subtree over idx[lo, hi).  Reports how the parent must refer
+  // to it: an inner node index (count 0) or a leaf (~lo, count).
+  void build(uint32_t lo, uint32_t hi, uint32_t depth, int32_t* child, int32_t* count, Box* box) {
+    const uint32_t cnt = hi - lo;
+    Box bounds, cbounds;
+    bounds.reset();
+    cbounds.reset();
+    for (uint32_t i = lo; i < hi; ++i) {
+      const size_t t = (size_t)idx[i] * 3;
+      bounds.grow(&tmin[t], &tmax[t]);
+      cbounds.grow_point(&cent[t]);
+    }
+    *box = bounds;
+    uint32_t d = max_depth.load(std::memory_order_relaxed);
+    while (depth > d && !max_depth.compare_exchange_weak(d, depth, std::memory_order_relaxed)) {}
+
+    auto make_leaf = [&]() {
+      *child = ~(int32_t)((lo << 2) | (cnt - 1));  // leaf reference: first triangle and count - 1 in one word
+      *count = (int32_t)cnt;
+    };
+    if (cnt == 1) { make_leaf(); return; }
+
+    uint32_t mid = lo;
+    bool have_split = false;
+    if (depth < kSahDepthLimit) {
+      float best_cost = INFINITY;
+      int best_axis = -1, best_bin = -1;
+      for (int axis = 0; axis < 3; ++axis) {
+        const float c0 = cbounds.mn[axis], extent = cbounds.mx[axis] - c0;
+        if (!(extent > 0.0f)) continue;
+        const float scale = (float)kBins / extent;
+        Box bin_box[kBins];
+        uint32_t bin_cnt[kBins] = {0};
+        for (int b = 0; b < kBins; ++b) bin_box[b].reset();
+        for (uint32_t i = lo; i < hi; ++i) {
+          const size_t t = (size_t)idx[i] * 3;
+          int b = (int)((cent[t + axis] - c0) * scale);
+          b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+          bin_cnt[b]++;
+          bin_box[b].grow(&tmin[t], &tmax[t]);
+        }
+        float right_area[kBins];
+        uint32_t right_cnt[kBins];
+        Box acc;
+        acc.reset();
+        uint32_t c = 0;
+        for (int b = kBins - 1; b > 0; --b) {
+          acc.grow(bin_box[b]);
+          c += bin_cnt[b];
+          right_area[b] = acc.half_area();
+          right_cnt[b] = c;
+        }
+        acc.reset();
+        c = 0;
+        for (int b = 0; b < kBins - 1; ++b) {
+          acc.grow(bin_box[b]);
+          c += bin_cnt[b];
+          if (c == 0 || right_cnt[b + 1] == 0) continue;
+          const float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+        }
+      }
+      if (best_axis >= 0) {
+        // leaf cost n * A versus 1 traversal step + children
+        const float parent_area = bounds.half_area();
+        const float split_cost = 1.0f + (parent_area > 0.0f ? best_cost / parent_area : 0.0f);
+        if (cnt <= kMaxLeaf && (float)cnt <= split_cost) { make_leaf(); return; }
+        const float c0 = cbounds.mn[best_axis];
+        const float scale = (float)kBins / (cbounds.mx[best_axis] - c0);
+        uint32_t* m = std::partition(idx + lo, idx + hi, [&](uint32_t t) {
+          int b = (int)((cent[(size_t)t * 3 + best_axis] - c0) * scale);
+          b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+          return b <= best_bin;
+        });
+        mid = (uint32_t)(m - idx);
+        have_split = mid > lo && mid < hi;
+      }
+    }
+    if (!have_split) {
+      if (cnt <= kMaxLeaf) { make_leaf(); return; }
+      // object median along the widest centroid axis (all centroids equal, or too deep for SAH)
+      int axis = 0;
+      for (int k = 1; k < 3; ++k)
+        if (cbounds.mx[k] - cbounds.mn[k] > cbounds.mx[axis] - cbounds.mn[axis]) axis = k;
+      mid = lo + cnt / 2;
+      std::nth_element(idx + lo, idx + mid, idx + hi, [&](uint32_t a, uint32_t b) {
+        return cent[(size_t)a * 3 + axis] < cent[(size_t)b * 3 + axis];
+      });
+    }
+
+    const uint32_t me = node_count.fetch_add(1, std::memory_order_relaxed);
+    BvhNode node;
+    std::memset(&node, 0, sizeof(node));
+    Box lb, rb;
+    int32_t lc, lcount, rc, rcount;
+    bool spawned = false;
+    std::thread worker;
+    if (cnt >= kSpawnThreshold && free_threads.fetch_sub(1, std::memory_order_relaxed) > 0) {
+      spawned = true;
+      worker = std::thread([&]() { build(lo, mid, depth + 1, &lc, &lcount, &lb); });
+    } else if (cnt >= kSpawnThreshold) {
+      free_threads.fetch_add(1, std::memory_order_relaxed);
+    }
+    if (!spawned) build(lo, mid, depth + 1, &lc, &lcount, &lb);
+    build(mid, hi, depth + 1, &rc, &rcount, &rb);
+    if (spawned) {
+      worker.join();
+      free_threads.fetch_add(1, std::memory_order_relaxed);
+    }
+    for (int k = 0; k < 3; ++k) {
+      node.lmin[k] = lb.mn[k]; node.lmax[k] = lb.mx[k];
+      node.rmin[k] = rb.mn[k]; node.rmax[k] = rb.mx[k];
+    }
+    node.left = lc; node.lcount = lcount;
+    node.right = rc; node.rcount = rcount;
+    nodes[me] = node;
+    *child = (int32_t)me;
+    *count = 0;
+  }
+};
+
+// Rewrites the nodes in depth-first pre-order so that a node's left child
+// follows it in memory.
+void relayout(const BvhNode* in, BvhNode* out, uint32_t n_nodes) {
+  if (n_nodes == 0) return;
+  std::vector<std::pair<uint32_t, uint32_t>> stack;  // (old index, slot in `out` of the reference to patch: parent*2+side)
+  uint32_t next = 0;
+  stack.emplace_back(0u, UINT32_MAX);
+  while (!stack.empty()) {
+    const auto [old_i, patch] = stack.back();
+    stack.pop_back();
+    const uint32_t me = next++;
+    out[me] = in[old_i];
+    if (patch != UINT32_MAX) {
+      if (patch & 1) out[patch >> 1].right = (int32_t)me;
+      else out[patch >> 1].left = (int32_t)me;
+    }
+    // push right first so that the left subtree is emitted first
+    if (in[old_i].rcount == 0 && in[old_i].right >= 0) stack.emplace_back((uint32_t)in[old_i].right, me * 2 + 1);
+    if (in[old_i].lcount == 0 && in[old_i].left >= 0) stack.emplace_back((uint32_t)in[old_i].left, me * 2);
+  }
+}
+
+}  // namespace
+
+bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuildResult* out) {
+  *out = BvhBuildResult();
+  const uint32_t cap = n_tris > 1 ? n_tris : 1;
+  BvhNode* scratch = (BvhNode*)std::malloc(sizeof(BvhNode) * (size_t)cap);
+  uint32_t* order = (uint32_t*)std::malloc(sizeof(uint32_t) * (size_t)cap);
+  if (!scratch || !order) { std::free(scratch); std::free(order); return false; }
+
+  auto empty_child = [](float* mn, float* mx) {
+    for (int k = 0; k < 3; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
+  };
+  uint32_t n_nodes = 0;
+  uint32_t depth = 0;
+  if (n_tris == 0) {
+    BvhNode root;
+    std::memset(&root, 0, sizeof(root));
+    empty_child(root.lmin, root.lmax);
+    empty_child(root.rmin, root.rmax);
+    root.left = root.right = ~0;
+    scratch[0] = root;
+    n_nodes = 1;
+  } else {
+    Builder b;
+    b.pos = tri_pos;
+    b.n = n_tris;
+    b.idx = order;
+    b.nodes = scratch;
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    if (threads > 64) threads = 64;
+    b.free_threads = (int)threads - 1;
+    for (uint32_t i = 0; i < n_tris; ++i) order[i] = i;
+    b.prepare();
+    int32_t child, count;
+    Box box;
+    b.build(0, n_tris, 0, &child, &count, &box);
+    n_nodes = b.node_count.load();
+    depth = b.max_depth.load();
+    if (count > 0) {  // the whole scene is one leaf: wrap it in a root node
+      BvhNode root;
+      std::memset(&root, 0, sizeof(root));
+      for (int k = 0; k < 3; ++k) { root.lmin[k] = box.mn[k]; root.lmax[k] = box.mx[k]; }
+      empty_child(root.rmin, root.rmax);
+      root.left = child;
+      root.lcount = count;
+      root.right = ~0;
+      root.rcount = 0;
+      scratch[0] = root;
+      n_nodes = 1;
+    }
+  }
+  BvhNode* nodes = (BvhNode*)std::malloc(sizeof(BvhNode) * (size_t)n_nodes);
+  if (!nodes) { std::free(scratch); std::free(order); return false; }
+  // the root of a multi-node tree is whichever node the top-level call allocated: index 0
+  relayout(scratch, nodes, n_nodes);
+  std::free(scratch);
+  out->nodes = nodes;
+  out->n_nodes = n_nodes;
+  out->order = order;
+  out->max_depth = depth;
+  return true;
+}
+
+void free_bvh(BvhBuildResult* r) {
+  std::free(r->nodes);
+  std::free(r->order);
+  *r = BvhBuildResult();
+}
+
+}  // namespace rrt

@@ -1,0 +1,830 @@
+// C ABI of librrt_hip.so (include/rrt.h): context, scene upload, camera, film,
+// the per-batch launch sequence of the wavefront path tracer, parity hooks,
+// statistics and the single-process RCCL film reduce.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rrt.h"
+#include "rrt_device.h"
+#include "rrt_kernels.h"
+
+using namespace rrt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr uint32_t kDefaultMaxSlots = 32u << 20;  // paths kept in flight per batch
+constexpr int kBlock = 256;
+
+struct EventPair {
+  hipEvent_t begin, end;
+  int stage;  // 0 raygen, 1 extend, 2 shade, 3 connect, 4 film
+};
+
+}  // namespace
+
+struct rrt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+
+  // scene
+  bool have_scene = false;
+  BvhNode* d_nodes = nullptr;
+  TriIsect* d_tris = nullptr;
+  TriShade* d_tri_shade = nullptr;
+  DeviceMaterial* d_materials = nullptr;
+  SceneTables* d_scene = nullptr;
+  uint8_t* d_env = nullptr;
+  SceneTables h_scene;
+  uint32_t n_nodes = 0;
+  uint64_t bvh_bytes = 0;
+
+  // camera
+  bool have_camera = false;
+  CameraParams camera;
+
+  // film
+  float* d_film = nullptr;
+  bool film_owned = false;
+  uint32_t film_w = 0, film_h = 0;
+
+  // path state
+  PathArrays arrays{};
+  std::vector<void*> state_allocs;
+  uint32_t state_slots = 0, state_depth = 0;
+  bool state_has_mis = false;
+
+  DeviceStats* d_stats = nullptr;
+
+  // options
+  bool timing = false;
+  bool count_traversal = false;
+  uint32_t batch_samples = 0;
+  uint32_t max_slots = kDefaultMaxSlots;
+
+  // timing
+  std::vector<EventPair> events;
+  size_t events_used = 0;
+  double ms[5] = {0, 0, 0, 0, 0};
+  uint64_t launches_extend = 0;
+};
+
+namespace {
+
+int fail(rrt_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->error = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail(ctx, RRT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+int bind_device(rrt_ctx* ctx) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return RRT_OK;
+}
+
+void free_scene(rrt_ctx* ctx) {
+  (void)hipFree(ctx->d_nodes);
+  (void)hipFree(ctx->d_tris);
+  (void)hipFree(ctx->d_tri_shade);
+  (void)hipFree(ctx->d_materials);
+  (void)hipFree(ctx->d_scene);
+  (void)hipFree(ctx->d_env);
+  ctx->d_nodes = nullptr;
+  ctx->d_tris = nullptr;
+  ctx->d_tri_shade = nullptr;
+  ctx->d_materials = nullptr;
+  ctx->d_scene = nullptr;
+  ctx->d_env = nullptr;
+  ctx->have_scene = false;
+}
+
+void free_state(rrt_ctx* ctx) {
+  for (void* p : ctx->state_allocs) (void)hipFree(p);
+  ctx->state_allocs.clear();
+  ctx->arrays = PathArrays{};
+  ctx->state_slots = 0;
+  ctx->state_depth = 0;
+}
+
+template <typename T>
+int dev_alloc(rrt_ctx* ctx, T** out, size_t count) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+  if (e != hipSuccess) return fail(ctx, RRT_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  *out = (T*)p;
+  return RRT_OK;
+}
+
+template <typename T>
+int state_alloc(rrt_ctx* ctx, T** out, size_t count) {
+  int rc = dev_alloc(ctx, out, count);
+  if (rc == RRT_OK) ctx->state_allocs.push_back(*out);
+  return rc;
+}
+
+// Path state for n_slots paths and `depth` bounces; grows only.
+int ensure_state(rrt_ctx* ctx, uint32_t n_slots, uint32_t depth, bool need_mis) {
+  if (ctx->state_slots >= n_slots && ctx->state_depth >= depth && (ctx->state_has_mis || !need_mis)) return RRT_OK;
+  free_state(ctx);
+  PathArrays& a = ctx->arrays;
+  int rc;
+  float4** main_arrays[] = {&a.ray_o, &a.ray_d, &a.beta, &a.radiance, &a.hit, &a.sh_o, &a.sh_d, &a.sh_c};
+  for (float4** arr : main_arrays)
+    if ((rc = state_alloc(ctx, arr, n_slots)) != RRT_OK) return rc;
+  if (need_mis) {
+    float4** mis_arrays[] = {&a.mis_o, &a.mis_d, &a.mis_c};
+    for (float4** arr : mis_arrays)
+      if ((rc = state_alloc(ctx, arr, n_slots)) != RRT_OK) return rc;
+  }
+  if ((rc = state_alloc(ctx, &a.queue[0], n_slots)) != RRT_OK) return rc;
+  if ((rc = state_alloc(ctx, &a.queue[1], n_slots)) != RRT_OK) return rc;
+  if ((rc = state_alloc(ctx, &a.sh_queue, n_slots)) != RRT_OK) return rc;
+  if ((rc = state_alloc(ctx, &a.live_count, 2 * (size_t)depth + 2)) != RRT_OK) return rc;
+  a.sh_count = a.live_count + depth + 1;
+  ctx->state_slots = n_slots;
+  ctx->state_depth = depth;
+  ctx->state_has_mis = need_mis;
+  return RRT_OK;
+}
+
+void norm3(const double* v, float* out) {
+  const double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  for (int k = 0; k < 3; ++k) out[k] = (float)(v[k] / l);
+}
+void cross3(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// helpers::coordinate_system (src/helpers.rs:73-83) in f64 on the host
+void coordinate_system_host(const double* v1, double* v2, double* v3) {
+  if (std::fabs(v1[0]) > std::fabs(v1[1])) {
+    const double l = std::sqrt(v1[0] * v1[0] + v1[2] * v1[2]);
+    v2[0] = -v1[2] / l; v2[1] = 0.0; v2[2] = v1[0] / l;
+  } else {
+    const double l = std::sqrt(v1[1] * v1[1] + v1[2] * v1[2]);
+    v2[0] = 0.0; v2[1] = v1[2] / l; v2[2] = -v1[1] / l;
+  }
+  cross3(v1, v2, v3);
+}
+
+// The lobes compute_scattering_functions adds for one material (materials/*.rs).
+DeviceMaterial digest_material(const rrt_material& m) {
+  DeviceMaterial d;
+  std::memset(&d, 0, sizeof(d));
+  const bool kd_zero = m.kd[0] == 0.0 && m.kd[1] == 0.0 && m.kd[2] == 0.0;
+  const bool ks_zero = m.ks[0] == 0.0 && m.ks[1] == 0.0 && m.ks[2] == 0.0;
+  d.ior = (float)m.ior;
+  switch (m.kind) {
+    case RRT_MAT_MATTE: {  // matte.rs:26-40
+      const double sigma = std::min(std::max(m.roughness, 0.0), 90.0);
+      if (!kd_zero) {
+        for (int k = 0; k < 3; ++k) d.diffuse[k] = (float)m.kd[k];
+        if (sigma == 0.0) {
+          d.diffuse_kind = DIFF_LAMBERT;
+        } else {
+          d.diffuse_kind = DIFF_OREN_NAYAR;  // OrenNayar::new takes the raw roughness (oren_nayar.rs:17-27)
+          const double s2 = m.roughness * m.roughness;
+          d.oren_a = (float)(1.0 - (s2 / (2.0 * (s2 + 0.33))));
+          d.oren_b = (float)(0.45 * s2 / (s2 + 0.09));
+        }
+      }
+      break;
+    }
+    case RRT_MAT_PLASTIC: {  // plastic.rs:36-65
+      if (!kd_zero) {
+        for (int k = 0; k < 3; ++k) d.diffuse[k] = (float)m.kd[k];
+        d.diffuse_kind = DIFF_LAMBERT;
+      }
+      if (!ks_zero) {
+        for (int k = 0; k < 3; ++k) d.spec[k] = (float)m.ks[k];
+        if (m.roughness < 1.0e-3) {
+          d.spec_kind = SPEC_MIRROR_DIELECTRIC;
+        } else {
+          d.spec_kind = SPEC_MICROFACET;
+          const double r = std::max(m.roughness, 1.0e-3);  // roughness_to_alpha, microfacet_distribution.rs:127-142
+          d.alpha = (float)(r * r);
+        }
+      }
+      break;
+    }
+    case RRT_MAT_MIRROR:  // mirror.rs:21-30
+      for (int k = 0; k < 3; ++k) d.spec[k] = (float)m.kd[k];
+      d.spec_kind = SPEC_MIRROR_NOOP;
+      break;
+    case RRT_MAT_GLASS:  // glass.rs:32-48: transmission (refraction colour) first, then reflection
+      for (int k = 0; k < 3; ++k) { d.trans[k] = (float)m.ks[k]; d.spec[k] = (float)m.kd[k]; }
+      d.has_trans = 1;
+      d.spec_kind = SPEC_MIRROR_DIELECTRIC;
+      break;
+    default: break;
+  }
+  d.n_lobes = (d.has_trans ? 1 : 0) + (d.diffuse_kind != DIFF_NONE ? 1 : 0) + (d.spec_kind != SPEC_NONE ? 1 : 0);
+  return d;
+}
+
+int record_begin(rrt_ctx* ctx, int stage) {
+  if (!ctx->timing) return RRT_OK;
+  if (ctx->events_used == ctx->events.size()) {
+    EventPair ep;
+    HIP_TRY(ctx, hipEventCreate(&ep.begin));
+    HIP_TRY(ctx, hipEventCreate(&ep.end));
+    ctx->events.push_back(ep);
+  }
+  ctx->events[ctx->events_used].stage = stage;
+  HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].begin, ctx->stream));
+  return RRT_OK;
+}
+
+int record_end(rrt_ctx* ctx) {
+  if (!ctx->timing) return RRT_OK;
+  HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].end, ctx->stream));
+  ctx->events_used++;
+  return RRT_OK;
+}
+
+int collect_timing(rrt_ctx* ctx) {
+  if (!ctx->timing || ctx->events_used == 0) return RRT_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < ctx->events_used; ++i) {
+    float ms = 0.0f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->events[i].begin, ctx->events[i].end));
+    ctx->ms[ctx->events[i].stage] += ms;
+    if (ctx->events[i].stage == 1) ctx->launches_extend++;
+  }
+  ctx->events_used = 0;
+  return RRT_OK;
+}
+
+inline uint32_t grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
+// One batch: tiles [tile_begin, tile_begin + n_tiles) x samples [sample_begin, sample_begin + k).
+int launch_batch(rrt_ctx* ctx, RenderParams& p) {
+  const uint32_t depth = p.depth_limit;
+  // the counter block was sized for the deepest render so far; lay this render's two arrays out in it
+  p.a.sh_count = p.a.live_count + depth + 1;
+  HIP_TRY(ctx, hipMemsetAsync(p.a.live_count, 0, sizeof(uint32_t) * (2 * (size_t)depth + 2), ctx->stream));
+  const uint32_t grid = grid_for(p.n_slots);
+  int rc;
+  if ((rc = record_begin(ctx, 0)) != RRT_OK) return rc;
+  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera);
+  if ((rc = record_end(ctx)) != RRT_OK) return rc;
+  for (uint32_t b = 0; b < depth; ++b) {
+    if ((rc = record_begin(ctx, 1)) != RRT_OK) return rc;
+    if (ctx->count_traversal) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
+    if ((rc = record_end(ctx)) != RRT_OK) return rc;
+    if ((rc = record_begin(ctx, 2)) != RRT_OK) return rc;
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
+    if ((rc = record_end(ctx)) != RRT_OK) return rc;
+    if ((rc = record_begin(ctx, 3)) != RRT_OK) return rc;
+    if (ctx->count_traversal) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
+    else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
+    if ((rc = record_end(ctx)) != RRT_OK) return rc;
+  }
+  if ((rc = record_begin(ctx, 4)) != RRT_OK) return rc;
+  hipLaunchKernelGGL(k_film, dim3(grid_for(p.n_tiles * 64)), dim3(kBlock), 0, ctx->stream, p);
+  hipLaunchKernelGGL(k_batch_stats, dim3(1), dim3(64), 0, ctx->stream, p);
+  if ((rc = record_end(ctx)) != RRT_OK) return rc;
+  HIP_TRY(ctx, hipGetLastError());
+  return collect_timing(ctx);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rrt_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+    return RRT_E_DEVICE;
+  }
+  return n;
+}
+
+rrt_ctx* rrt_create(int device) {
+  int n = rrt_device_count();
+  if (n <= 0) {
+    if (n == 0) g_create_error = "no HIP device visible";
+    return nullptr;
+  }
+  if (device < 0 || device >= n) {
+    g_create_error = "device index out of range";
+    return nullptr;
+  }
+  rrt_ctx* ctx = new (std::nothrow) rrt_ctx();
+  if (!ctx) {
+    g_create_error = "out of host memory";
+    return nullptr;
+  }
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&ctx->d_stats, sizeof(DeviceStats)) != hipSuccess ||
+      hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess) {
+    g_create_error = "cannot initialise device " + std::to_string(device);
+    delete ctx;
+    return nullptr;
+  }
+  return ctx;
+}
+
+void rrt_destroy(rrt_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_scene(ctx);
+  free_state(ctx);
+  if (ctx->film_owned) (void)hipFree(ctx->d_film);
+  (void)hipFree(ctx->d_stats);
+  for (EventPair& e : ctx->events) {
+    (void)hipEventDestroy(e.begin);
+    (void)hipEventDestroy(e.end);
+  }
+  delete ctx;
+}
+
+int rrt_set_stream(rrt_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  ctx->stream = (hipStream_t)hip_stream;
+  return RRT_OK;
+}
+
+int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* sd) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!sd) return fail(ctx, RRT_E_INVALID, "null scene");
+  if (sd->n_tris && (!sd->tri_pos || !sd->tri_nrm || !sd->tri_mat)) return fail(ctx, RRT_E_INVALID, "null triangle arrays");
+  if ((sd->n_rects && !sd->rects) || (sd->n_planes && !sd->planes) || (sd->n_spheres && !sd->spheres) ||
+      (sd->n_materials && !sd->materials) || (sd->n_lights && !sd->lights))
+    return fail(ctx, RRT_E_INVALID, "null table");
+  if (sd->n_rects > RRT_MAX_RECTS || sd->n_planes > RRT_MAX_PLANES || sd->n_spheres > RRT_MAX_SPHERES ||
+      sd->n_lights > RRT_MAX_LIGHTS)
+    return fail(ctx, RRT_E_UNSUPPORTED, "too many analytic shapes or lights for the device tables");
+  if (sd->n_tris >= (1u << 29)) return fail(ctx, RRT_E_UNSUPPORTED, "more than 2^29 triangles");
+  if (sd->rect_aabb_mode > RRT_RECT_AABB_OFF) return fail(ctx, RRT_E_INVALID, "bad rect_aabb_mode");
+  for (uint32_t i = 0; i < sd->n_tris; ++i)
+    if (sd->tri_mat[i] >= sd->n_materials) return fail(ctx, RRT_E_INVALID, "triangle material index out of range");
+  for (uint32_t i = 0; i < sd->n_rects; ++i)
+    if (sd->rects[i].material >= sd->n_materials || sd->rects[i].light >= (int32_t)sd->n_lights)
+      return fail(ctx, RRT_E_INVALID, "rectangle material / light index out of range");
+  for (uint32_t i = 0; i < sd->n_planes; ++i)
+    if (sd->planes[i].material >= sd->n_materials) return fail(ctx, RRT_E_INVALID, "plane material index out of range");
+  for (uint32_t i = 0; i < sd->n_spheres; ++i)
+    if (sd->spheres[i].material >= sd->n_materials) return fail(ctx, RRT_E_INVALID, "sphere material index out of range");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  free_scene(ctx);
+
+  // ---- BVH over the triangles, then the leaf-ordered records
+  BvhBuildResult bvh;
+  if (!build_bvh(sd->tri_pos, sd->n_tris, 0, &bvh)) return fail(ctx, RRT_E_NOMEM, "BVH build: out of host memory");
+  std::vector<TriIsect> tris(sd->n_tris);
+  std::vector<TriShade> shade(sd->n_tris);
+  for (uint32_t slot = 0; slot < sd->n_tris; ++slot) {
+    const uint32_t id = bvh.order[slot];
+    const float* p = sd->tri_pos + (size_t)id * 9;
+    const float* n = sd->tri_nrm + (size_t)id * 9;
+    TriIsect& t = tris[slot];
+    uint32_t bits = id;
+    float idf;
+    std::memcpy(&idf, &bits, 4);
+    t.v0 = float4{p[0], p[1], p[2], idf};
+    t.e1 = float4{p[3] - p[0], p[4] - p[1], p[5] - p[2], 0.0f};
+    t.e2 = float4{p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.0f};
+    bits = sd->tri_mat[id];
+    float matf;
+    std::memcpy(&matf, &bits, 4);
+    shade[slot].n0 = float4{n[0], n[1], n[2], matf};
+    shade[slot].n1 = float4{n[3], n[4], n[5], 0.0f};
+    shade[slot].n2 = float4{n[6], n[7], n[8], 0.0f};
+  }
+
+  // ---- small tables
+  SceneTables& st = ctx->h_scene;
+  std::memset(&st, 0, sizeof(st));
+  st.n_tris = (int)sd->n_tris;
+  st.n_rects = (int)sd->n_rects;
+  st.n_planes = (int)sd->n_planes;
+  st.n_spheres = (int)sd->n_spheres;
+  st.n_lights = (int)sd->n_lights;
+  st.n_materials = (int)sd->n_materials;
+  st.rect_aabb_mode = (int)sd->rect_aabb_mode;
+  st.infinite_light = -1;
+  for (uint32_t i = 0; i < sd->n_rects; ++i) {
+    const rrt_rect& r = sd->rects[i];
+    DeviceRect& q = st.rects[i];
+    double n[3], nn[3], ss[3], ts[3];
+    cross3(r.side_a, r.side_b, n);
+    const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    for (int k = 0; k < 3; ++k) nn[k] = n[k] / l;
+    coordinate_system_host(nn, ss, ts);
+    double aa = 0, bb = 0;
+    for (int k = 0; k < 3; ++k) {
+      q.pos[k] = (float)r.pos[k]; q.a[k] = (float)r.side_a[k]; q.b[k] = (float)r.side_b[k];
+      q.normal[k] = (float)nn[k]; q.ss[k] = (float)ss[k]; q.ts[k] = (float)ts[k];
+      aa += r.side_a[k] * r.side_a[k]; bb += r.side_b[k] * r.side_b[k];
+      const double opp = r.pos[k] + r.side_a[k] + r.side_b[k];  // objects/rectangle.rs:138-145
+      q.bmin[k] = (float)std::min(r.pos[k], opp);
+      q.bmax[k] = (float)std::max(r.pos[k], opp);
+    }
+    q.inv_aa = (float)(1.0 / aa);
+    q.inv_bb = (float)(1.0 / bb);
+    q.material = (int)r.material;
+    q.light = r.light;
+  }
+  for (uint32_t i = 0; i < sd->n_planes; ++i) {
+    const rrt_plane& pl = sd->planes[i];
+    DevicePlane& d = st.planes[i];
+    for (int k = 0; k < 3; ++k) { d.pos[k] = (float)pl.pos[k]; d.normal[k] = (float)pl.normal[k]; }
+    const double flip = pl.normal[1] < 0.0 ? -1.0 : 1.0;  // face_forward(normal, (0,1,0)), surface_interaction.rs:57
+    for (int k = 0; k < 3; ++k) d.ng[k] = (float)(flip * pl.normal[k]);
+    d.material = (int)pl.material;
+  }
+  for (uint32_t i = 0; i < sd->n_spheres; ++i) {
+    const rrt_sphere& s = sd->spheres[i];
+    for (int k = 0; k < 3; ++k) st.spheres[i].center[k] = (float)s.center[k];
+    st.spheres[i].radius = (float)s.radius;
+    st.spheres[i].material = (int)s.material;
+  }
+  for (uint32_t i = 0; i < sd->n_lights; ++i) {
+    const rrt_light& l = sd->lights[i];
+    DeviceLight& d = st.lights[i];
+    d.kind = (int)l.kind;
+    d.rect = -1;
+    for (int k = 0; k < 3; ++k) {
+      d.intensity[k] = (float)l.intensity[k];
+      d.v0[k] = (float)l.v0[k]; d.v1[k] = (float)l.v1[k]; d.v2[k] = (float)l.v2[k];
+    }
+    if (l.kind == RRT_LIGHT_AREA) {
+      double n[3];
+      cross3(l.v1, l.v2, n);
+      norm3(n, d.normal);
+      d.area = (float)(l.v2[0] * l.v2[0] + l.v2[1] * l.v2[1] + l.v2[2] * l.v2[2]);  // |side_b|^2, rectangle.rs:131-133
+      for (uint32_t r = 0; r < sd->n_rects; ++r)
+        if (sd->rects[r].light == (int32_t)i) d.rect = (int)r;
+    } else if (l.kind == RRT_LIGHT_DISTANT) {
+      norm3(l.v0, d.v0);  // DistantLight::new normalises (lights/distant.rs:81)
+      for (int k = 0; k < 3; ++k) st.distant_env[k] += (float)l.intensity[k];
+    } else if (l.kind == RRT_LIGHT_INFINITE) {
+      if (!sd->env_rgb8 || !sd->env_w || !sd->env_h) {
+        free_bvh(&bvh);
+        return fail(ctx, RRT_E_INVALID, "infinite light without environment texels");
+      }
+      st.infinite_light = (int)i;
+    } else if (l.kind != RRT_LIGHT_POINT) {
+      free_bvh(&bvh);
+      return fail(ctx, RRT_E_INVALID, "unknown light kind");
+    }
+  }
+  st.has_env = st.infinite_light >= 0 ? 1 : 0;
+  st.env_w = (int)sd->env_w;
+  st.env_h = (int)sd->env_h;
+  std::vector<DeviceMaterial> mats(sd->n_materials);
+  for (uint32_t i = 0; i < sd->n_materials; ++i) mats[i] = digest_material(sd->materials[i]);
+
+  // ---- upload
+  ctx->n_nodes = bvh.n_nodes;
+  rc = dev_alloc(ctx, &ctx->d_nodes, bvh.n_nodes);
+  if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_tris, sd->n_tris);
+  if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_tri_shade, sd->n_tris);
+  if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_materials, sd->n_materials);
+  if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_scene, 1);
+  if (rc == RRT_OK && st.has_env) rc = dev_alloc(ctx, &ctx->d_env, (size_t)sd->env_w * sd->env_h * 3);
+  if (rc != RRT_OK) { free_bvh(&bvh); free_scene(ctx); return rc; }
+  hipError_t e = hipMemcpy(ctx->d_nodes, bvh.nodes, sizeof(BvhNode) * (size_t)bvh.n_nodes, hipMemcpyHostToDevice);
+  if (e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tris, tris.data(), sizeof(TriIsect) * tris.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tri_shade, shade.data(), sizeof(TriShade) * shade.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && sd->n_materials) e = hipMemcpy(ctx->d_materials, mats.data(), sizeof(DeviceMaterial) * mats.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(ctx->d_scene, &st, sizeof(st), hipMemcpyHostToDevice);
+  if (e == hipSuccess && st.has_env) e = hipMemcpy(ctx->d_env, sd->env_rgb8, (size_t)sd->env_w * sd->env_h * 3, hipMemcpyHostToDevice);
+  free_bvh(&bvh);
+  if (e != hipSuccess) { free_scene(ctx); return fail(ctx, RRT_E_DEVICE, std::string("scene upload: ") + hipGetErrorString(e)); }
+  ctx->bvh_bytes = sizeof(BvhNode) * (uint64_t)ctx->n_nodes + (sizeof(TriIsect) + sizeof(TriShade)) * (uint64_t)sd->n_tris;
+  ctx->have_scene = true;
+  return RRT_OK;
+}
+
+int rrt_set_camera(rrt_ctx* ctx, const double raster_to_camera[16], const double camera_to_world[16], double aperture,
+                   double focal_distance) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!raster_to_camera || !camera_to_world) return fail(ctx, RRT_E_INVALID, "null matrix");
+  std::memcpy(ctx->camera.raster_to_camera, raster_to_camera, sizeof(double) * 16);
+  std::memcpy(ctx->camera.camera_to_world, camera_to_world, sizeof(double) * 16);
+  ctx->camera.aperture = aperture;
+  ctx->camera.focal_distance = focal_distance;
+  ctx->have_camera = true;
+  return RRT_OK;
+}
+
+int rrt_film_alloc(rrt_ctx* ctx, uint32_t width, uint32_t height) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!width || !height) return fail(ctx, RRT_E_INVALID, "empty film");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  if (ctx->film_owned) (void)hipFree(ctx->d_film);
+  ctx->d_film = nullptr;
+  ctx->film_owned = false;
+  rc = dev_alloc(ctx, &ctx->d_film, (size_t)width * height * 4);
+  if (rc != RRT_OK) return rc;
+  ctx->film_owned = true;
+  ctx->film_w = width;
+  ctx->film_h = height;
+  return rrt_film_clear(ctx);
+}
+
+int rrt_film_bind(rrt_ctx* ctx, float* device_ptr, uint32_t width, uint32_t height) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!device_ptr || !width || !height) return fail(ctx, RRT_E_INVALID, "bad film binding");
+  if (((uintptr_t)device_ptr & 15u) != 0) return fail(ctx, RRT_E_INVALID, "film pointer must be 16-byte aligned");
+  if (ctx->film_owned) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipFree(ctx->d_film);
+  }
+  ctx->d_film = device_ptr;
+  ctx->film_owned = false;
+  ctx->film_w = width;
+  ctx->film_h = height;
+  return RRT_OK;
+}
+
+int rrt_film_clear(rrt_ctx* ctx) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!ctx->d_film) return fail(ctx, RRT_E_STATE, "no film");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_film, 0, sizeof(float) * 4 * (size_t)ctx->film_w * ctx->film_h, ctx->stream));
+  return RRT_OK;
+}
+
+int rrt_film_download(rrt_ctx* ctx, float* host) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!host) return fail(ctx, RRT_E_INVALID, "null destination");
+  if (!ctx->d_film) return fail(ctx, RRT_E_STATE, "no film");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(host, ctx->d_film, sizeof(float) * 4 * (size_t)ctx->film_w * ctx->film_h,
+                              hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return RRT_OK;
+}
+
+void* rrt_film_device_ptr(rrt_ctx* ctx) { return ctx ? ctx->d_film : nullptr; }
+
+int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint32_t sample_end) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!s) return fail(ctx, RRT_E_INVALID, "null settings");
+  if (!ctx->have_scene) return fail(ctx, RRT_E_STATE, "no scene uploaded");
+  if (!ctx->have_camera) return fail(ctx, RRT_E_STATE, "no camera set");
+  if (!ctx->d_film) return fail(ctx, RRT_E_STATE, "no film");
+  if (s->width != ctx->film_w || s->height != ctx->film_h) return fail(ctx, RRT_E_INVALID, "settings do not match the film size");
+  if (s->crop_x0 > s->crop_x1 || s->crop_y0 > s->crop_y1 || s->crop_x1 > s->width || s->crop_y1 > s->height)
+    return fail(ctx, RRT_E_INVALID, "crop window outside the film");
+  if (sample_end < sample_begin) return fail(ctx, RRT_E_INVALID, "empty or reversed sample range");
+  if ((uint64_t)s->width * s->height > 0xffffffffull) return fail(ctx, RRT_E_UNSUPPORTED, "film too large");
+  const uint32_t win_w = s->crop_x1 - s->crop_x0, win_h = s->crop_y1 - s->crop_y0;
+  const uint32_t n_samples = sample_end - sample_begin;
+  if (win_w == 0 || win_h == 0 || n_samples == 0 || s->depth_limit == 0) return RRT_OK;
+  if (s->depth_limit > 4096) return fail(ctx, RRT_E_UNSUPPORTED, "depth_limit above 4096");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+
+  const uint32_t tiles_x = (win_w + 7) / 8, tiles_y = (win_h + 7) / 8;
+  const uint64_t total_tiles = (uint64_t)tiles_x * tiles_y;
+  // batch shape: as many samples per pixel as fit (all of a pixel's samples sit in
+  // consecutive slots), and if one sample of the whole window does not fit, tile ranges
+  const uint64_t max_slots = ctx->max_slots;
+  uint32_t k = ctx->batch_samples ? ctx->batch_samples : (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, max_slots / (total_tiles * 64)));
+  k = std::min(k, n_samples);
+  const uint32_t tiles_per_batch = (uint32_t)std::min<uint64_t>(total_tiles, std::max<uint64_t>(1, max_slots / (64ull * k)));
+  const bool need_mis = ctx->h_scene.has_env != 0;
+  rc = ensure_state(ctx, tiles_per_batch * 64 * k, s->depth_limit, need_mis);
+  if (rc != RRT_OK) return rc;
+
+  RenderParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.a = ctx->arrays;
+  p.nodes = ctx->d_nodes;
+  p.tris = ctx->d_tris;
+  p.tri_shade = ctx->d_tri_shade;
+  p.materials = ctx->d_materials;
+  p.scene = ctx->d_scene;
+  p.env = ctx->d_env;
+  p.stats = ctx->d_stats;
+  p.film = ctx->d_film;
+  p.seed = s->seed;
+  p.width = s->width;
+  p.height = s->height;
+  p.win_x0 = s->crop_x0;
+  p.win_y0 = s->crop_y0;
+  p.win_w = win_w;
+  p.win_h = win_h;
+  p.tiles_x = tiles_x;
+  p.depth_limit = s->depth_limit;
+  p.clamp = (float)s->clamp;
+  for (uint64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_batch) {
+    p.tile_begin = (uint32_t)t0;
+    p.n_tiles = (uint32_t)std::min<uint64_t>(tiles_per_batch, total_tiles - t0);
+    for (uint32_t s0 = sample_begin; s0 < sample_end; s0 += k) {
+      p.sample_begin = s0;
+      p.n_samples = std::min(k, sample_end - s0);
+      p.n_slots = p.n_tiles * 64 * p.n_samples;
+      if ((rc = launch_batch(ctx, p)) != RRT_OK) return rc;
+    }
+  }
+  return RRT_OK;
+}
+
+int rrt_synchronize(rrt_ctx* ctx) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return RRT_OK;
+}
+
+int rrt_intersect(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_t* prim_id, float* t) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!ctx->have_scene) return fail(ctx, RRT_E_STATE, "no scene uploaded");
+  if (n == 0) return RRT_OK;
+  if (!org_dir || !prim_id || !t) return fail(ctx, RRT_E_INVALID, "null array");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  float* d_rays = nullptr;
+  int32_t* d_prim = nullptr;
+  float* d_t = nullptr;
+  rc = dev_alloc(ctx, &d_rays, (size_t)n * 6);
+  if (rc == RRT_OK) rc = dev_alloc(ctx, &d_prim, n);
+  if (rc == RRT_OK) rc = dev_alloc(ctx, &d_t, n);
+  hipError_t e = hipSuccess;
+  if (rc == RRT_OK) {
+    e = hipMemcpyAsync(d_rays, org_dir, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_intersect, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes, ctx->d_tris,
+                         ctx->d_scene, d_rays, n, d_prim, d_t);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(prim_id, d_prim, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(d_rays);
+  (void)hipFree(d_prim);
+  (void)hipFree(d_t);
+  if (rc != RRT_OK) return rc;
+  if (e != hipSuccess) return fail(ctx, RRT_E_DEVICE, std::string("rrt_intersect: ") + hipGetErrorString(e));
+  return RRT_OK;
+}
+
+int rrt_occluded(rrt_ctx* ctx, const float* org_dir_tmax, uint32_t n, uint8_t* hit) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!ctx->have_scene) return fail(ctx, RRT_E_STATE, "no scene uploaded");
+  if (n == 0) return RRT_OK;
+  if (!org_dir_tmax || !hit) return fail(ctx, RRT_E_INVALID, "null array");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  float* d_rays = nullptr;
+  uint8_t* d_hit = nullptr;
+  rc = dev_alloc(ctx, &d_rays, (size_t)n * 7);
+  if (rc == RRT_OK) rc = dev_alloc(ctx, &d_hit, n);
+  hipError_t e = hipSuccess;
+  if (rc == RRT_OK) {
+    e = hipMemcpyAsync(d_rays, org_dir_tmax, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_occluded, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes, ctx->d_tris,
+                         ctx->d_scene, d_rays, n, d_hit);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hit, d_hit, (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(d_rays);
+  (void)hipFree(d_hit);
+  if (rc != RRT_OK) return rc;
+  if (e != hipSuccess) return fail(ctx, RRT_E_DEVICE, std::string("rrt_occluded: ") + hipGetErrorString(e));
+  return RRT_OK;
+}
+
+int rrt_set_option(rrt_ctx* ctx, int option, int64_t value) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  switch (option) {
+    case RRT_OPT_TIMING: ctx->timing = value != 0; return RRT_OK;
+    case RRT_OPT_BATCH_SAMPLES:
+      if (value < 0 || value > 4096) return fail(ctx, RRT_E_INVALID, "batch samples out of range");
+      ctx->batch_samples = (uint32_t)value;
+      return RRT_OK;
+    case RRT_OPT_MAX_SLOTS:
+      if (value < 64 || value > (int64_t)(1u << 30)) return fail(ctx, RRT_E_INVALID, "max slots out of range");
+      ctx->max_slots = (uint32_t)value;
+      return RRT_OK;
+    case RRT_OPT_COUNT_TRAVERSAL: ctx->count_traversal = value != 0; return RRT_OK;
+    default: return fail(ctx, RRT_E_INVALID, "unknown option");
+  }
+}
+
+int rrt_get_stats(rrt_ctx* ctx, rrt_stats* out) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!out) return fail(ctx, RRT_E_INVALID, "null destination");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  DeviceStats ds;
+  HIP_TRY(ctx, hipMemcpy(&ds, ctx->d_stats, sizeof(ds), hipMemcpyDeviceToHost));
+  std::memset(out, 0, sizeof(*out));
+  out->paths = ds.paths;
+  out->rays_extend = ds.rays_extend;
+  out->rays_shadow = ds.rays_shadow;
+  out->path_bounces = ds.path_bounces;
+  out->nodes_visited = ds.nodes_visited;
+  out->tris_tested = ds.tris_tested;
+  out->ms_raygen = ctx->ms[0];
+  out->ms_extend = ctx->ms[1];
+  out->ms_shade = ctx->ms[2];
+  out->ms_connect = ctx->ms[3];
+  out->ms_film = ctx->ms[4];
+  out->launches_extend = ctx->launches_extend;
+  out->bvh_nodes = ctx->n_nodes;
+  out->bvh_bytes = ctx->bvh_bytes;
+  return RRT_OK;
+}
+
+int rrt_reset_stats(rrt_ctx* ctx) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)));
+  for (double& m : ctx->ms) m = 0.0;
+  ctx->launches_extend = 0;
+  return RRT_OK;
+}
+
+// RCCL is loaded on first use so that single-GPU users never pay for it.
+int rrt_film_reduce(rrt_ctx** ctxs, int n, int root) {
+  if (!ctxs || n <= 0 || root < 0 || root >= n) return fail(nullptr, RRT_E_INVALID, "bad reduce arguments");
+  for (int i = 0; i < n; ++i)
+    if (!ctxs[i] || !ctxs[i]->d_film) return fail(ctxs[i], RRT_E_STATE, "context without a film");
+  for (int i = 1; i < n; ++i)
+    if (ctxs[i]->film_w != ctxs[0]->film_w || ctxs[i]->film_h != ctxs[0]->film_h)
+      return fail(ctxs[i], RRT_E_INVALID, "films differ in size");
+  if (n == 1) return RRT_OK;
+  typedef void* comm_t;
+  typedef int (*comm_init_all_t)(comm_t*, int, const int*);
+  typedef int (*reduce_t)(const void*, void*, size_t, int, int, int, comm_t, hipStream_t);
+  typedef int (*group_t)(void);
+  typedef int (*comm_destroy_t)(comm_t);
+  static void* lib = nullptr;
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return fail(ctxs[root], RRT_E_UNSUPPORTED, "librccl.so not found");
+  auto init_all = (comm_init_all_t)dlsym(lib, "ncclCommInitAll");
+  auto reduce = (reduce_t)dlsym(lib, "ncclReduce");
+  auto group_start = (group_t)dlsym(lib, "ncclGroupStart");
+  auto group_end = (group_t)dlsym(lib, "ncclGroupEnd");
+  auto comm_destroy = (comm_destroy_t)dlsym(lib, "ncclCommDestroy");
+  if (!init_all || !reduce || !group_start || !group_end || !comm_destroy)
+    return fail(ctxs[root], RRT_E_UNSUPPORTED, "RCCL symbols missing");
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+  std::vector<comm_t> comms(n);
+  if (init_all(comms.data(), n, devs.data()) != 0) return fail(ctxs[root], RRT_E_DEVICE, "ncclCommInitAll failed");
+  const size_t count = (size_t)ctxs[0]->film_w * ctxs[0]->film_h * 4;
+  int rc = RRT_OK;
+  group_start();
+  for (int i = 0; i < n; ++i) {
+    (void)hipSetDevice(ctxs[i]->device);
+    // ncclFloat32 = 7, ncclSum = 0
+    if (reduce(ctxs[i]->d_film, ctxs[i]->d_film, count, 7, 0, root, comms[i], ctxs[i]->stream) != 0) rc = RRT_E_DEVICE;
+  }
+  group_end();
+  for (int i = 0; i < n; ++i) {
+    (void)hipSetDevice(ctxs[i]->device);
+    (void)hipStreamSynchronize(ctxs[i]->stream);
+    comm_destroy(comms[i]);
+  }
+  if (rc != RRT_OK) return fail(ctxs[root], rc, "ncclReduce failed");
+  return RRT_OK;
+}
+
+const char* rrt_last_error(rrt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"

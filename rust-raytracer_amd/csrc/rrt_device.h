@@ -1,0 +1,135 @@
+// Device-resident data layout of the path-tracing core (shared by the host
+// BVH builder, the upload code and the kernels).  Everything the kernels read
+// is structure-of-arrays or 16-byte records so that one lane fetches a whole
+// record with dwordx4 loads.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rrt.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RRT_HD __host__ __device__
+#else
+#define RRT_HD
+struct float4 { float x, y, z, w; };
+struct uint4 { uint32_t x, y, z, w; };
+#endif
+
+namespace rrt {
+
+// One BVH2 node, 64 B = one 64-byte fetch: the boxes of both children and
+// where they lead.  child >= 0: index of an inner node.  child < 0: a leaf of
+// 1..4 triangles of the leaf-ordered triangle arrays, ~child = first << 2 |
+// (count - 1); lcount / rcount repeat the count (0 for an inner child).  An
+// absent child has count 0 and an inverted box that no ray enters.
+struct alignas(64) BvhNode {
+  float lmin[3], lmax[3];
+  float rmin[3], rmax[3];
+  int32_t left, right;
+  int32_t lcount, rcount;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+// Intersection record of a triangle, 48 B, leaf order: vertex 0 and the two
+// edges Moeller-Trumbore needs.  v0.w carries the scene-order object id.
+struct TriIsect {
+  float4 v0;  // xyz = p0, w = bits of scene-order id
+  float4 e1;  // xyz = p1 - p0
+  float4 e2;  // xyz = p2 - p0
+};
+
+// Shading record of a triangle, 48 B, leaf order: the three vertex normals
+// (objects/triangle.rs:84-107).  n0.w carries the material index bits.
+struct TriShade {
+  float4 n0, n1, n2;
+};
+
+enum DiffuseKind : int { DIFF_NONE = 0, DIFF_LAMBERT = 1, DIFF_OREN_NAYAR = 2 };
+enum SpecKind : int { SPEC_NONE = 0, SPEC_MIRROR_DIELECTRIC = 1, SPEC_MICROFACET = 2, SPEC_MIRROR_NOOP = 3 };
+
+// A material pre-digested into the lobes compute_scattering_functions would
+// add (materials/*.rs), in the order they are added: transmission, diffuse,
+// specular.
+struct DeviceMaterial {
+  float diffuse[3];
+  int diffuse_kind;
+  float spec[3];
+  int spec_kind;
+  float trans[3];
+  int has_trans;
+  float oren_a, oren_b;
+  float alpha;  // Trowbridge-Reitz alpha_x = alpha_y
+  float ior;
+  int n_lobes;
+  int _pad[3];
+};
+
+struct DeviceRect {
+  float pos[3], a[3], b[3];
+  float normal[3];     // normalize(a x b)
+  float ss[3], ts[3];  // coordinate_system(normal)
+  float inv_aa, inv_bb;
+  float bmin[3], bmax[3];  // the f32 box the reference's pre-filter tests
+  int material;
+  int light;
+};
+
+struct DevicePlane {
+  float pos[3], normal[3];
+  float ng[3];  // face_forward(normal, (0,1,0))
+  int material;
+};
+
+struct DeviceSphere {
+  float center[3];
+  float radius;
+  int material;
+};
+
+struct DeviceLight {
+  int kind;
+  float intensity[3];
+  float v0[3], v1[3], v2[3];  // see rrt_light
+  float normal[3];            // area: normalize(a x b)
+  float area;                 // area: |side_b|^2 (objects/rectangle.rs:131-133)
+  int rect;                   // area: index of its quad in rects[], -1 if none
+};
+
+#define RRT_MAX_RECTS 16
+#define RRT_MAX_PLANES 4
+#define RRT_MAX_SPHERES 16
+#define RRT_MAX_LIGHTS 16
+
+// Small tables, passed to kernels by pointer to one device copy.
+struct SceneTables {
+  int n_tris, n_rects, n_planes, n_spheres, n_lights, n_materials;
+  int rect_aabb_mode;
+  int has_env;
+  int env_w, env_h;
+  float distant_env[3];  // sum of DistantLight intensities: what every escaping ray picks up (lights/distant.rs:62-64)
+  int infinite_light;    // index of the InfiniteArea light or -1
+  DeviceRect rects[RRT_MAX_RECTS];
+  DevicePlane planes[RRT_MAX_PLANES];
+  DeviceSphere spheres[RRT_MAX_SPHERES];
+  DeviceLight lights[RRT_MAX_LIGHTS];
+};
+
+struct CameraParams {
+  double raster_to_camera[16];
+  double camera_to_world[16];
+  double aperture, focal_distance;
+};
+
+// Host BVH builder (bvh_build.cpp).  Produces nodes and the leaf order.
+struct BvhBuildResult {
+  BvhNode* nodes = nullptr;      // malloc'ed, n_nodes entries, node 0 is the root
+  uint32_t n_nodes = 0;
+  uint32_t* order = nullptr;     // malloc'ed, n_tris entries: leaf slot -> scene-order triangle
+  uint32_t max_depth = 0;
+};
+// tri_pos: [n][3][3] floats.  threads = 0: hardware concurrency.  Returns false on allocation failure.
+bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuildResult* out);
+void free_bvh(BvhBuildResult* r);
+
+}  // namespace rrt
