@@ -42,6 +42,7 @@ def _load(name, rel):
 
 rr = _load("rust_raytracer_amd", "rust-raytracer_amd/__init__.py")
 standin = _load("rust_raytracer_amd.standin", "rust-raytracer_amd/standin.py")
+rrdist = _load("rust_raytracer_amd.distributed", "rust-raytracer_amd/distributed.py")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # algorithmic bytes per ray: 64 B per BVH node visited (two child boxes + links), 36 B per triangle
@@ -132,13 +133,12 @@ def main():
     if args.batch_samples:
         ctx.set_option(rr.OPT_BATCH_SAMPLES, args.batch_samples)
     settings = rr.make_settings(W, H, rs.depth_limit, rs.clamp, seed=0)
-    s_begin, s_end = rank * SPP, (rank + 1) * SPP
+    s_begin, s_end = rrdist.weak_sample_range(rank, SPP)
 
     def step():
         film.zero_()
         ctx.render(settings, s_begin, s_end)
-        if dist is not None:
-            dist.reduce(film, dst=0)
+        rrdist.reduce_film(film, dst=0)  # RCCL sum onto rank 0; a no-op on one GPU
 
     def fence():
         if dist is not None:

@@ -44,6 +44,8 @@ def lib():
         L.orc_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_intersect_margin.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_occluded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.orc_philox4x32_10.restype = None
         L.orc_rng.restype = C.c_double
         L.orc_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_triangle_intersect.argtypes = [dp, dp, dp, dp, dp, dp, dp, dp]
@@ -64,6 +66,7 @@ def lib():
         L.orc_tr_pdf.argtypes = [dp, dp, C.c_double, C.c_double, C.c_int]
         L.orc_microfacet_f.argtypes = [dp, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp]
         L.orc_specular_reflection_sample_f.argtypes = [dp, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp]
+        L.orc_specular_reflection_f_pdf.argtypes = [dp, dp, dp, dp, dp]
         L.orc_tonemap_pixel.argtypes = [dp, C.c_void_p]
         _lib = L
     return _lib

@@ -1664,6 +1664,12 @@ int orc_occluded(orc_ctx* ctx, const double* odt, uint32_t n, uint8_t* hit) {
   return RRT_OK;
 }
 
+void orc_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c[4] = {counter[0], counter[1], counter[2], counter[3]};
+  philox4x32_10(c, key[0], key[1]);
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+
 double orc_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t block, uint32_t index) {
   return rng_block(seed, pixel, sample, block).u[index & 3];
 }
@@ -1733,6 +1739,14 @@ void orc_specular_reflection_sample_f(const double r[3], int fresnel_kind, doubl
   wi[0] = w.x; wi[1] = w.y; wi[2] = w.z;
   *pdf = p;
   f[0] = ff.x; f[1] = ff.y; f[2] = ff.z;
+}
+void orc_specular_reflection_f_pdf(const double r[3], const double wo[3], const double wi[3], double f[3], double* pdf) {
+  Bxdf b;
+  b.kind = Bxdf::SpecularReflection;
+  b.color = v3(r);
+  const V3 ff = b.f(v3(wo), v3(wi));
+  f[0] = ff.x; f[1] = ff.y; f[2] = ff.z;
+  *pdf = b.pdf(v3(wo), v3(wi));
 }
 void orc_tonemap_pixel(const double radiance[3], uint8_t rgb[3]) {
   const double x = radiance[0], y = radiance[1], z = radiance[2];

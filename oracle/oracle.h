@@ -71,7 +71,9 @@ int orc_occluded(orc_ctx* ctx, const double* org_dir_tmax, uint32_t n, uint8_t* 
 int orc_intersect_margin(orc_ctx* ctx, const double* org_dir, uint32_t n, int32_t* prim_id, double* t,
                          double* margin);
 
-/* The random number stream both implementations draw from. */
+/* The random number stream both implementations draw from: raw Philox4x32-10 and the [0,1) draw
+ * index 0..3 of block `block` of camera path (pixel, sample). */
+void orc_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 double orc_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t block, uint32_t index);
 
 /* ---- single functions, exposed for the reference's known-answer tests ---- */
@@ -94,6 +96,8 @@ void orc_microfacet_f(const double r[3], double ax, double ay, double eta_i, dou
 /* SpecularReflection::sample_f / f / pdf (bsdf/specular_reflection.rs:22-42); fresnel_kind 0 = Noop, 1 = Dielectric */
 void orc_specular_reflection_sample_f(const double r[3], int fresnel_kind, double eta_i, double eta_t,
                                       const double wo[3], double wi[3], double* pdf, double f[3]);
+/* SpecularReflection::f and ::pdf (bsdf/specular_reflection.rs:27-33). */
+void orc_specular_reflection_f_pdf(const double r[3], const double wo[3], const double wi[3], double f[3], double* pdf);
 /* Film tone map of one pixel (src/film.rs:236-247). */
 void orc_tonemap_pixel(const double radiance[3], uint8_t rgb[3]);
 

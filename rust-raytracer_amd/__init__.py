@@ -218,6 +218,7 @@ class Scene:
         d = SceneDesc()
         if host_lib().rrth_scene_desc(self._h, C.byref(d)) != 0:
             raise RrtError(host_lib().rrth_last_error().decode())
+        d._owner = self  # the pointers in `d` stay valid only while the scene lives
         return d
 
     def set_rect_aabb_mode(self, mode):
@@ -238,6 +239,71 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+class SceneArrays:
+    """A scene assembled in Python: the same flat arrays Scene::load_from_folder produces, filled in
+    by hand (for scenes that have no folder: tests, generated stress scenes)."""
+
+    def __init__(self, tri_pos=None, tri_nrm=None, tri_mat=None, materials=(), lights=(), rects=(), planes=(),
+                 spheres=(), env_rgb8=None, rect_aabb_mode=RECT_AABB_STRICT):
+        n = 0 if tri_pos is None else len(tri_pos)
+        self.tri_pos = np.ascontiguousarray(np.zeros((0, 3, 3)) if tri_pos is None else tri_pos, dtype=np.float32)
+        self.tri_nrm = np.ascontiguousarray(np.zeros((0, 3, 3)) if tri_nrm is None else tri_nrm, dtype=np.float32)
+        self.tri_mat = np.ascontiguousarray(np.zeros(n) if tri_mat is None else tri_mat, dtype=np.uint32)
+        assert self.tri_pos.shape == (n, 3, 3) and self.tri_nrm.shape == (n, 3, 3) and self.tri_mat.shape == (n,)
+        self.materials = (Material * max(1, len(materials)))(*materials)
+        self.lights = (Light * max(1, len(lights)))(*lights)
+        self.rects = (Rect * max(1, len(rects)))(*rects)
+        self.planes = (Plane * max(1, len(planes)))(*planes)
+        self.spheres = (Sphere * max(1, len(spheres)))(*spheres)
+        self.counts = (n, len(rects), len(planes), len(spheres), len(materials), len(lights))
+        self.env = None if env_rgb8 is None else np.ascontiguousarray(env_rgb8, dtype=np.uint8)
+        self.rect_aabb_mode = rect_aabb_mode
+
+    def desc(self):
+        d = SceneDesc()
+        d.n_tris, d.n_rects, d.n_planes, d.n_spheres, d.n_materials, d.n_lights = self.counts
+        d.tri_pos = self.tri_pos.ctypes.data_as(C.POINTER(C.c_float))
+        d.tri_nrm = self.tri_nrm.ctypes.data_as(C.POINTER(C.c_float))
+        d.tri_mat = self.tri_mat.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.materials = C.cast(self.materials, C.POINTER(Material))
+        d.lights = C.cast(self.lights, C.POINTER(Light))
+        d.rects = C.cast(self.rects, C.POINTER(Rect))
+        d.planes = C.cast(self.planes, C.POINTER(Plane))
+        d.spheres = C.cast(self.spheres, C.POINTER(Sphere))
+        if self.env is not None:
+            d.env_rgb8 = self.env.ctypes.data_as(C.POINTER(C.c_uint8))
+            d.env_h, d.env_w = self.env.shape[:2]
+        d.rect_aabb_mode = self.rect_aabb_mode
+        d._owner = self
+        return d
+
+
+def make_light(kind, intensity=(1, 1, 1), v0=(0, 0, 0), v1=(0, 0, 0), v2=(0, 0, 0)):
+    l = Light()
+    l.kind = kind
+    l.intensity, l.v0, l.v1, l.v2 = _vec3(intensity), _vec3(v0), _vec3(v1), _vec3(v2)
+    return l
+
+
+def make_rect(pos, side_a, side_b, material, light=-1):
+    r = Rect()
+    r.pos, r.side_a, r.side_b = _vec3(pos), _vec3(side_a), _vec3(side_b)
+    r.material, r.light = material, light
+    return r
+
+
+def make_plane(pos, normal, material):
+    p = Plane()
+    p.pos, p.normal, p.material = _vec3(pos), _vec3(normal), material
+    return p
+
+
+def make_sphere(center, radius, material):
+    s = Sphere()
+    s.center, s.radius, s.material = _vec3(center), float(radius), material
+    return s
 
 
 def load_render_settings(folder):
@@ -338,7 +404,7 @@ class Context:
         self._check(self._lib.rrt_set_stream(self._h, stream_ptr), "rrt_set_stream")
 
     def upload_scene(self, scene):
-        d = scene.desc() if isinstance(scene, Scene) else scene
+        d = scene.desc() if hasattr(scene, "desc") else scene
         self._check(self._lib.rrt_upload_scene(self._h, C.byref(d)), "rrt_upload_scene")
 
     def set_camera(self, camera):

@@ -1,0 +1,78 @@
+"""Test scenes that exercise the parts of the hot path the shipped scenes do not reach."""
+import os
+
+import numpy as np
+
+
+def mixed_scene(rrt):
+    """Every shape, material and light kind in one small scene.
+
+    Teapot (992 triangles, microfacet plastic) on a two-triangle matte floor, under the area,
+    distant and environment lights of scenes/mixed/scene.yaml, plus what the loader never builds but
+    the integrator supports: an infinite Plane with a mirror-lobe plastic, a glass Sphere, a mirror
+    Sphere, an Oren-Nayar Sphere and a point light.  Returns (SceneArrays, render settings, folder).
+    """
+    folder = os.path.join(rrt.SCENES, "mixed")
+    base = rrt.Scene.load_from_folder(folder)
+    d = base.desc()
+    pos = np.ctypeslib.as_array(d.tri_pos, shape=(d.n_tris, 3, 3)).copy()
+    nrm = np.ctypeslib.as_array(d.tri_nrm, shape=(d.n_tris, 3, 3)).copy()
+    pos = pos * np.float32(0.1) + np.array([0.0, 0.8, 0.0], dtype=np.float32)
+    env = np.ctypeslib.as_array(d.env_rgb8, shape=(d.env_h, d.env_w, 3)).copy()
+
+    floor_pos = np.array([[[-4, 0, -4], [4, 0, 4], [4, 0, -4]], [[-4, 0, -4], [-4, 0, 4], [4, 0, 4]]], dtype=np.float32)
+    floor_nrm = np.tile(np.array([0, 1, 0], dtype=np.float32), (2, 3, 1))
+    tri_pos = np.concatenate([pos, floor_pos])
+    tri_nrm = np.concatenate([nrm, floor_nrm])
+    tri_mat = np.concatenate([np.zeros(len(pos)), np.ones(2)]).astype(np.uint32)
+
+    materials = [
+        rrt.make_material(rrt.MAT_PLASTIC, kd=(0.6, 0.3, 0.2), ks=(1, 1, 1), roughness=0.3, ior=1.5),   # 0 teapot
+        rrt.make_material(rrt.MAT_MATTE, kd=(0.7, 0.7, 0.7), roughness=0.0),                             # 1 floor: Lambertian
+        d.materials[1],                                                                                  # 2 light quad: Matte(0.9, 20)
+        rrt.make_material(rrt.MAT_GLASS, kd=(1, 1, 1), ks=(0.95, 0.95, 0.95), ior=1.5),                  # 3
+        rrt.make_material(rrt.MAT_MIRROR, kd=(0.9, 0.9, 0.9)),                                           # 4
+        rrt.make_material(rrt.MAT_MATTE, kd=(0.2, 0.5, 0.8), roughness=0.6),                             # 5 Oren-Nayar
+        rrt.make_material(rrt.MAT_PLASTIC, kd=(0.3, 0.3, 0.3), ks=(0.5, 0.5, 0.5), roughness=0.0, ior=1.8),  # 6 mirror-lobe plastic
+    ]
+    lights = [d.lights[i] for i in range(d.n_lights)]
+    assert [l.kind for l in lights] == [rrt.LIGHT_AREA, rrt.LIGHT_DISTANT, rrt.LIGHT_INFINITE]
+    lights.insert(2, rrt.make_light(rrt.LIGHT_POINT, intensity=(6, 6, 5), v0=(-2.5, 2.5, -2.0)))  # environment light stays last
+    rect = d.rects[0]
+    rects = [rrt.make_rect(rect.pos[:], rect.side_a[:], rect.side_b[:], material=2, light=0)]
+    planes = [rrt.make_plane((0, -0.5, 0), (0, 1, 0), material=6)]
+    spheres = [rrt.make_sphere((2.2, 0.7, -0.5), 0.7, 3), rrt.make_sphere((-2.2, 0.7, 0.3), 0.7, 4),
+               rrt.make_sphere((0.3, 0.4, -2.2), 0.4, 5)]
+    scene = rrt.SceneArrays(tri_pos, tri_nrm, tri_mat, materials, lights, rects, planes, spheres, env)
+    rs = rrt.load_render_settings(folder)
+    return scene, rs, folder
+
+
+def camera_rays(rrt, rs, w, h, n, seed):
+    cam = rrt.Camera.from_settings(rs, w, h)
+    rng = np.random.default_rng(seed)
+    rays = np.empty((n, 6))
+    for i in range(n):
+        o, d = cam.generate_ray(rng.uniform(0, w), rng.uniform(0, h))
+        rays[i, :3], rays[i, 3:] = o, d
+    return rays
+
+
+def bounce_rays(oracle, rays, rng):
+    """Secondary rays: from just in front of each hit point into a random direction."""
+    prim, t = oracle.intersect(rays)
+    hit = prim >= 0
+    p = rays[hit, :3] + rays[hit, 3:] * t[hit, None] * (1 - 1e-3)
+    d = rng.normal(size=p.shape)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([p, d], axis=1)
+
+
+def ray_set(rrt, oracle, rs, n_primary, seed):
+    """Camera rays plus two generations of bounce rays, rounded to f32 (what the device can hold)."""
+    rng = np.random.default_rng(seed + 100)
+    primary = camera_rays(rrt, rs, 256, 256, n_primary, seed)
+    first = bounce_rays(oracle, primary, rng)
+    second = bounce_rays(oracle, first, rng)
+    rays = np.concatenate([primary, first, second])
+    return rays.astype(np.float32).astype(np.float64)

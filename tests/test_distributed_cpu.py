@@ -1,0 +1,83 @@
+"""The N > 1 path on CPU: two gloo ranks shard the sample range, render their share (with the CPU
+oracle standing in for the GPU, which this machine does not have) and sum the films onto rank 0.
+The union must equal the single-process render of the whole range."""
+import importlib.util
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_distributed():
+    spec = importlib.util.spec_from_file_location("rrt_distributed", os.path.join(ROOT, "rust-raytracer_amd", "distributed.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_sample_ranges_partition():
+    d = _load_distributed()
+    for world in (1, 2, 3, 4, 8):
+        for total in (1, 7, 256, 4096):
+            ranges = [d.sample_range(r, world, total) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            sizes = [e - b for b, e in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    assert [d.weak_sample_range(r, 256) for r in range(3)] == [(0, 256), (256, 512), (512, 768)]
+    with pytest.raises(ValueError):
+        d.sample_range(2, 2, 10)
+
+
+def _worker(rank, world, port, mode, out_path):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    from oracle import binding as ob
+
+    rr = conftest.rr
+    d = _load_distributed()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    folder = os.path.join(rr.SCENES, "cornell")
+    scene = rr.Scene.load_from_folder(folder)
+    rs = rr.load_render_settings(folder)
+    w, h, spp = 24, 24, 6
+    orc = ob.Oracle(scene.desc())
+    orc.set_camera(rr.Camera.from_settings(rs, w, h))
+    s = rr.make_settings(w, h, 4, rs.clamp, seed=12)
+    b, e = d.sample_range(rank, world, spp) if mode == "strong" else d.weak_sample_range(rank, spp)
+    film, _ = orc.render(s, b, e, threads=1)
+    t = torch.from_numpy(film.astype(np.float32))
+    d.reduce_film(t, dst=0)
+    if rank == 0:
+        np.save(out_path, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["strong", "weak"])
+def test_two_rank_render_equals_one(rrt, oracle_binding, cornell, tmp_path, mode):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    out = str(tmp_path / "film.npy")
+    mp.spawn(_worker, args=(2, port, mode, out), nprocs=2, join=True)
+    got = np.load(out)
+    scene, rs = cornell
+    orc = oracle_binding.Oracle(scene.desc())
+    orc.set_camera(rrt.Camera.from_settings(rs, 24, 24))
+    s = rrt.make_settings(24, 24, 4, rs.clamp, seed=12)
+    total = 6 if mode == "strong" else 12
+    ref, _ = orc.render(s, 0, total, threads=2)
+    assert (got[..., 3] == total).all()
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)

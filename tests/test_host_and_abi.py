@@ -1,0 +1,240 @@
+"""CPU-only checks of the host mirror (loader, settings, tone map) and of the two C ABIs."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# --------------------------------------------------------------------------- ABI
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rrth?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(rrt):
+    hip, host = rrt.hip_lib(), rrt.host_lib()
+    names = _declared("rrt.h")
+    assert set(names) == set(rrt.RRT_SYMBOLS), set(names) ^ set(rrt.RRT_SYMBOLS)
+    for n in names:
+        assert getattr(hip, n) is not None
+    names = _declared("rrt_host.h")
+    assert set(names) == set(rrt.RRTH_SYMBOLS), set(names) ^ set(rrt.RRTH_SYMBOLS)
+    for n in names:
+        assert getattr(host, n) is not None
+
+
+def test_struct_sizes_match_the_header(rrt, tmp_path):
+    """ctypes mirrors must have the C layout: compile a tiny program that prints sizeof()."""
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "rrt.h"\n#include "rrt_host.h"\nint main(void){printf("%zu %zu %zu %zu %zu '
+                   '%zu %zu %zu %zu\\n", sizeof(rrt_material), sizeof(rrt_light), sizeof(rrt_rect), sizeof(rrt_plane), '
+                   'sizeof(rrt_sphere), sizeof(rrt_scene_desc), sizeof(rrt_settings), sizeof(rrt_stats), '
+                   'sizeof(rrth_render_settings));return 0;}\n')
+    exe = tmp_path / "sizes"
+    import subprocess
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    mirrors = [rrt.Material, rrt.Light, rrt.Rect, rrt.Plane, rrt.Sphere, rrt.SceneDesc, rrt.Settings, rrt.Stats,
+               rrt.RenderSettingsFile]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+def test_null_and_state_errors_do_not_crash(rrt):
+    lib = rrt.hip_lib()
+    assert lib.rrt_set_stream(None, None) == -1
+    assert lib.rrt_upload_scene(None, None) == -1
+    assert lib.rrt_render(None, None, 0, 1) == -1
+    assert lib.rrt_film_download(None, None) == -1
+    assert lib.rrt_get_stats(None, None) == -1
+    assert lib.rrt_film_reduce(None, 0, 0) == -1
+    assert lib.rrt_film_device_ptr(None) is None
+    lib.rrt_destroy(None)
+    assert isinstance(lib.rrt_last_error(None), bytes)
+
+
+def test_without_a_gpu_the_product_fails_loudly(rrt):
+    """No CPU fallback: where no HIP device is visible, creating a context raises."""
+    n = rrt.hip_lib().rrt_device_count()
+    if n > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(rrt.RrtError):
+        rrt.Context(0)
+
+
+# --------------------------------------------------------------------------- loader
+def test_cornell_scene(rrt, cornell):
+    scene, rs = cornell
+    d = scene.desc()
+    # asset census: 2007 quads -> 4014 fan triangles, one area light -> one quad
+    assert (d.n_tris, d.n_rects, d.n_planes, d.n_spheres, d.n_lights) == (4014, 1, 0, 0, 1)
+    assert d.n_materials == 10  # nine OBJ models + Matte(0.9, 20) of the light quad
+    assert d.env_w == 0 and not d.env_rgb8  # environment_map is commented out in scene.yaml
+    mats = [d.materials[i] for i in range(d.n_materials)]
+    assert all(m.kind == rrt.MAT_PLASTIC for m in mats[:9])
+    # the three pillars: Pr 0 -> mirror lobe, ior 1.85; the sphere: Pr 0.271676, Ks 1
+    assert [m.roughness for m in mats[:3]] == [0.0, 0.0, 0.0]
+    assert mats[0].ior == pytest.approx(1.85, rel=1e-6)
+    assert mats[8].roughness == pytest.approx(0.271676) and list(mats[8].ks) == [1.0, 1.0, 1.0]
+    assert mats[9].kind == rrt.MAT_MATTE and mats[9].roughness == 20.0 and list(mats[9].kd) == [0.9] * 3
+    light = d.lights[0]
+    assert light.kind == rrt.LIGHT_AREA and list(light.v0) == [-0.5, 0.99, -0.5]
+    assert list(light.v1) == [1.0, 0.0, 0.0] and list(light.v2) == [0.0, 0.0, 1.0]
+    assert d.rects[0].light == 0 and d.rects[0].material == 9
+    tri_mat = np.ctypeslib.as_array(d.tri_mat, shape=(d.n_tris,))
+    assert np.bincount(tri_mat).tolist() == [12, 12, 12, 2, 2, 2, 2, 2, 3968]
+    nrm = np.ctypeslib.as_array(d.tri_nrm, shape=(d.n_tris, 3, 3))
+    np.testing.assert_allclose(np.linalg.norm(nrm, axis=2), 1.0, atol=1e-3)
+    # settings as main() reads them
+    assert (rs.image_width, rs.image_height, rs.max_samples, rs.depth_limit, rs.threads) == (1000, 1000, 12, 8, 11)
+    assert rs.clamp == 10.0 and rs.filter_method == 0 and rs.denoise == 0
+    assert (rs.crop_x0, rs.crop_y0, rs.crop_x1, rs.crop_y1) == (0, 0, 1000, 1000)
+    assert rs.has_focal_distance == 1 and rs.focal_distance == 0.0  # "0.0" is a value, not "absent"
+
+
+def test_buddha_scene_files(rrt):
+    folder = os.path.join(rrt.SCENES, "buddha")
+    rs = rrt.load_render_settings(folder)
+    assert (rs.image_width, rs.image_height, rs.max_samples, rs.depth_limit) == (2000, 2000, 100, 12)
+    assert rs.aperture == 0.1 and rs.has_focal_distance == 0 and rs.window_scale == 1.5
+    assert (rs.crop_x0, rs.crop_y0, rs.crop_x1, rs.crop_y1) == (0, 0, 2000, 2000)  # "crop:" holds only comments
+    cam = rrt.Camera.from_settings(rs, 200, 200)
+    assert cam.focal_distance == pytest.approx(np.linalg.norm(np.array([0, 3.2, -0.5]) - np.array([3, 2, -8])))
+    pos = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], dtype=np.float32)
+    nrm = np.array([[[0, 0, 1]] * 3], dtype=np.float32)
+    scene = rrt.Scene.load_from_folder_with_mesh(folder, pos, nrm, rrt.make_material(rrt.MAT_MATTE, kd=(1, 1, 1)))
+    d = scene.desc()
+    kinds = [d.lights[i].kind for i in range(d.n_lights)]
+    assert kinds == [rrt.LIGHT_AREA] * 3 + [rrt.LIGHT_DISTANT, rrt.LIGHT_INFINITE]  # yaml order, environment last
+    assert d.n_rects == 3 and [d.rects[i].light for i in range(3)] == [0, 1, 2]
+    assert (d.env_w, d.env_h) == (750, 375)
+    env = np.ctypeslib.as_array(d.env_rgb8, shape=(375, 750, 3))
+    assert env.max() <= 255 and env.mean() > 10
+
+
+def test_environment_texel_conversion(rrt, tmp_path):
+    """InfiniteAreaLight::new: texel -> srgb_to_xyz -> *255 -> min(255) -> truncate."""
+    folder = tmp_path / "s"
+    folder.mkdir()
+    (folder / "scene.yaml").write_text("world:\n  up_axis: y\nenvironment_map: e.ppm\nlights:\n")
+    px = np.array([[[255, 255, 255], [0, 0, 0]], [[128, 64, 32], [10, 200, 90]]], dtype=np.uint8)
+    with open(folder / "e.ppm", "wb") as f:
+        f.write(b"P6\n2 2\n255\n" + px.tobytes())
+    scene = rrt.Scene.load_from_folder(str(folder))
+    d = scene.desc()
+    got = np.ctypeslib.as_array(d.env_rgb8, shape=(2, 2, 3))
+
+    def inv_gamma(v):
+        return np.where(v <= 0, 0.0, np.where(v < 0.04045, v / 12.92, np.where(v < 1.0, ((v + 0.055) / 1.055) ** 2.4, 1.0)))
+
+    m = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    want = np.minimum((inv_gamma(px / 255.0) @ m.T) * 255.0, 255.0).astype(np.uint8)
+    np.testing.assert_array_equal(got, want)
+    assert d.n_lights == 1 and d.lights[0].kind == rrt.LIGHT_INFINITE
+
+
+def _write_scene(folder, obj, mtl, yaml_extra=""):
+    folder.mkdir(exist_ok=True)
+    (folder / "scene.yaml").write_text("world:\n  file: m.obj\n  up_axis: y\n" + yaml_extra)
+    (folder / "m.obj").write_text(obj)
+    (folder / "m.mtl").write_text(mtl)
+
+
+def test_obj_and_mtl_semantics(rrt, tmp_path):
+    obj = """mtllib m.mtl
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0.5 1.5 0
+vn 0 0 1
+vt 0.5 0.5
+o first
+usemtl glassy
+f 1//1 2//1 3//1 4//1 5//1
+usemtl dull
+f -5//-1 -4//-1 -3//-1
+o second
+f 1/1/1 2/1/1 3/1/1
+"""
+    mtl = """newmtl glassy
+Kd 0.1 0.2 0.3
+Tf 0.9 0.8 0.7
+Ni 1.33
+newmtl dull
+Kd 0.5 0.5 0.5
+Ks 0.25 0.25 0.25
+Ni 1.6
+"""
+    _write_scene(tmp_path / "a", obj, mtl)
+    d = rrt.Scene.load_from_folder(str(tmp_path / "a")).desc()
+    # pentagon -> 3 fan triangles; a usemtl change inside an object starts a new model; the
+    # current material carries over into the next object
+    assert d.n_tris == 5 and d.n_materials == 3
+    tri_mat = np.ctypeslib.as_array(d.tri_mat, shape=(5,)).tolist()
+    assert tri_mat == [0, 0, 0, 1, 2]
+    pos = np.ctypeslib.as_array(d.tri_pos, shape=(5, 3, 3))
+    np.testing.assert_array_equal(pos[1], [[0, 0, 0], [1, 1, 0], [0, 1, 0]])      # fan (0, 2, 3)
+    np.testing.assert_array_equal(pos[3], [[0, 0, 0], [1, 0, 0], [1, 1, 0]])      # negative indices
+    g, dull = d.materials[0], d.materials[1]
+    assert g.kind == rrt.MAT_GLASS and g.ior == pytest.approx(1.33, rel=1e-6)
+    assert list(g.ks) == [0.9, 0.8, 0.7] and list(g.kd) == pytest.approx([0.1, 0.2, 0.3], rel=1e-6)
+    # no Pr in the MTL -> roughness 32.0 (src/scene.rs:270-278)
+    assert dull.kind == rrt.MAT_PLASTIC and dull.roughness == 32.0 and dull.ior == pytest.approx(1.6, rel=1e-6)
+
+
+def test_mesh_without_normals_is_rejected(rrt, tmp_path):
+    _write_scene(tmp_path / "b", "mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n", "")
+    with pytest.raises(rrt.RrtError, match="normals"):
+        rrt.Scene.load_from_folder(str(tmp_path / "b"))
+
+
+def test_missing_files_raise(rrt, tmp_path):
+    with pytest.raises(rrt.RrtError):
+        rrt.Scene.load_from_folder(str(tmp_path / "nope"))
+    with pytest.raises(rrt.RrtError):
+        rrt.load_render_settings(str(tmp_path / "nope"))
+
+
+def test_yaml_typed_accessors(rrt, tmp_path):
+    """yaml-rust's as_f64() is None for an integer scalar: `clamp: 10` means no clamp (src/main.rs:256)."""
+    base = open(os.path.join(rrt.SCENES, "cornell", "render_settings.yaml")).read()
+    folder = tmp_path / "c"
+    folder.mkdir()
+    (folder / "render_settings.yaml").write_text(base.replace("clamp: 10.0", "clamp: 10"))
+    assert rrt.load_render_settings(str(folder)).clamp == 0.0
+    (folder / "render_settings.yaml").write_text(base.replace("#  crop:\n#    start: [300,300]\n#    end: [400,400]",
+                                                              "  crop:\n    start: [300,310]\n    end: [400,420]"))
+    rs = rrt.load_render_settings(str(folder))
+    assert (rs.crop_x0, rs.crop_y0, rs.crop_x1, rs.crop_y1) == (300, 310, 400, 420)
+    (folder / "render_settings.yaml").write_text(base.replace("fov: 38.0", "fov: 38"))
+    with pytest.raises(rrt.RrtError):  # .as_f64().unwrap() panics in the reference
+        rrt.load_render_settings(str(folder))
+
+
+# --------------------------------------------------------------------------- film
+def test_tonemap_matches_the_oracle_pixel(rrt, oracle_binding):
+    """Host Film tone map vs the oracle's restatement of src/film.rs:236-247 on random accumulators."""
+    rng = np.random.default_rng(0)
+    acc = np.zeros((8, 8, 4), dtype=np.float32)
+    acc[..., :3] = rng.uniform(0, 3, size=(8, 8, 3)).astype(np.float32) * rng.integers(1, 5, size=(8, 8, 1))
+    acc[..., 3] = rng.integers(1, 5, size=(8, 8))
+    acc[0, 0] = 0  # no samples: black
+    acc[0, 1] = [1, 1, 1, 1]
+    img = rrt.tonemap(acc)
+    L = oracle_binding.lib()
+    for y in range(8):
+        for x in range(8):
+            if acc[y, x, 3] == 0:
+                assert img[y, x].tolist() == [0, 0, 0]
+                continue
+            rad = (acc[y, x, :3].astype(np.float64) / float(acc[y, x, 3]))
+            out = (C.c_uint8 * 3)()
+            L.orc_tonemap_pixel((C.c_double * 3)(*rad), out)
+            assert img[y, x].tolist() == list(out)
+    # white (1,1,1) goes through the XYZ->sRGB matrix: (1.2048, 0.9483, 0.9089) before gamma
+    assert img[0, 1].tolist() == [255, int((0.948291 ** (1 / 2.4) * 1.055 - 0.055) * 255), int((0.908916 ** (1 / 2.4) * 1.055 - 0.055) * 255)]

@@ -1,0 +1,86 @@
+"""CPU-only checks of the oracle itself: it reproduces the committed golden vectors, and its
+renders have the properties any correct scheduler must have (independent of thread count, bucket
+size and of how the sample range is cut)."""
+import os
+
+import numpy as np
+import pytest
+
+import scenes_util
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def mixed(rrt):
+    return scenes_util.mixed_scene(rrt)
+
+
+def test_oracle_reproduces_golden_rays(oracle_binding, cornell, mixed):
+    for name, scene in (("cornell_rays.npz", cornell[0]), ("mixed_rays.npz", mixed[0])):
+        g = np.load(os.path.join(GOLDEN, name))
+        orc = oracle_binding.Oracle(scene.desc())
+        prim, t, margin = orc.intersect(g["rays"].astype(np.float64), with_margin=True)
+        np.testing.assert_array_equal(prim, g["prim"])
+        np.testing.assert_array_equal(t, g["t"])
+        np.testing.assert_array_equal(margin, g["margin"])
+        plain_prim, plain_t = orc.intersect(g["rays"].astype(np.float64))
+        np.testing.assert_array_equal(plain_prim, prim)
+        np.testing.assert_array_equal(plain_t, t)
+
+
+def test_oracle_reproduces_golden_films(rrt, oracle_binding, cornell, mixed):
+    cases = (("cornell_film_48x48_4spp_seed3.npy", cornell[0], cornell[1], 48, 48, 3),
+             ("mixed_film_80x60_4spp_seed4.npy", mixed[0], mixed[1], 80, 60, 4))
+    for name, scene, rs, w, h, seed in cases:
+        ref = np.load(os.path.join(GOLDEN, name))
+        orc = oracle_binding.Oracle(scene.desc())
+        orc.set_camera(rrt.Camera.from_settings(rs, w, h))
+        s = rrt.make_settings(w, h, rs.depth_limit, rs.clamp, seed=seed)
+        film, st = orc.render(s, 0, 4, threads=4)
+        assert st.paths == w * h * 4
+        # per-pixel sums are added in sample order whatever the thread count: exactly reproducible
+        np.testing.assert_array_equal(film, ref)
+
+
+def test_oracle_scheduler_independence(rrt, oracle_binding, cornell):
+    scene, rs = cornell
+    orc = oracle_binding.Oracle(scene.desc())
+    orc.set_camera(rrt.Camera.from_settings(rs, 40, 24))
+    s = rrt.make_settings(40, 24, 4, rs.clamp, seed=2, crop=(3, 2, 37, 23))
+    a, _ = orc.render(s, 0, 6, threads=1, bucket=(128, 128))
+    b, _ = orc.render(s, 0, 6, threads=5, bucket=(7, 5))
+    np.testing.assert_array_equal(a, b)
+    c, _ = orc.render(s, 0, 2, threads=3, bucket=(16, 16))
+    c, _ = orc.render(s, 2, 6, threads=3, bucket=(16, 16), film=c)
+    np.testing.assert_allclose(c, a, rtol=1e-12)
+    assert (a[..., 3][2:23, 3:37] == 6).all()
+    outside = np.ones((24, 40), bool)
+    outside[2:23, 3:37] = False
+    assert (a[outside] == 0).all()
+
+
+def test_oracle_trace_one_matches_render(rrt, oracle_binding, cornell):
+    scene, rs = cornell
+    orc = oracle_binding.Oracle(scene.desc())
+    orc.set_camera(rrt.Camera.from_settings(rs, 16, 16))
+    s = rrt.make_settings(16, 16, rs.depth_limit, rs.clamp, seed=6)
+    film, _ = orc.render(s, 3, 4, threads=2)
+    for (x, y) in ((0, 0), (7, 9), (15, 15), (8, 13)):
+        np.testing.assert_array_equal(orc.trace_one(s, x, y, 3), film[y, x, :3])
+
+
+def test_clamp_bounds_the_running_sum(rrt, oracle_binding, mixed):
+    """tracer.rs:116-120 clamps the running radiance; what a path adds after its last clamp is
+    bounded by the light it can collect in one bounce, so no sample is far above the clamp."""
+    scene, rs, _ = mixed
+    orc = oracle_binding.Oracle(scene.desc())
+    orc.set_camera(rrt.Camera.from_settings(rs, 40, 30))
+    lo, _ = orc.render(rrt.make_settings(40, 30, 6, 0.25, seed=1), 0, 1, threads=4)
+    hi, _ = orc.render(rrt.make_settings(40, 30, 6, 0.0, seed=1), 0, 1, threads=4)
+    assert hi[..., :3].max() > 1.0          # unclamped paths do get bright
+    assert lo[..., :3].sum() < hi[..., :3].sum()
+    # depth 1 never reaches the clamp line of a second bounce: clamp only applies if the path continues
+    d1a, _ = orc.render(rrt.make_settings(40, 30, 1, 0.25, seed=1), 0, 1, threads=4)
+    d1b, _ = orc.render(rrt.make_settings(40, 30, 1, 1e9, seed=1), 0, 1, threads=4)
+    assert (d1a[..., :3] <= d1b[..., :3] + 1e-12).all()
