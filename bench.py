@@ -67,16 +67,21 @@ def load_buddha(width, height):
     return scene, rs, camera, mesh
 
 
-def cpu_baseline(scene, rs, threads, budget_paths):
+def cpu_baseline(scene, rs, threads, budget_paths, budget_seconds=0.0):
     """Times the CPU oracle (port of the reference algorithm) on a bounded sample of the same workload:
     the same scene, camera, depth and clamp at 1/12 of the resolution in each direction."""
     from oracle import binding as ob
     w, h = 160, 90
-    spp = max(1, budget_paths // (w * h))
     cam = rr.Camera.from_settings(rs, w, h)
     orc = ob.Oracle(scene.desc())
     orc.set_camera(cam)
     s = rr.make_settings(w, h, rs.depth_limit, rs.clamp, seed=0)
+    if budget_seconds > 0:
+        # pilot pass to size the sample for about budget_seconds of CPU work
+        _, pilot = orc.render(s, 0, 2, threads=threads)
+        spp = int(min(4096, max(2, budget_seconds * pilot.paths / max(pilot.seconds, 1e-3) / (w * h))))
+    else:
+        spp = max(1, budget_paths // (w * h))
     _, st = orc.render(s, 0, spp, threads=threads)
     rays = st.rays_extend + st.rays_shadow
     return {
@@ -97,7 +102,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--cpu-paths", type=int, default=120000, help="camera paths of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline: seconds of oracle work (0 = use --cpu-paths)")
+    ap.add_argument("--cpu-paths", type=int, default=0, help="CPU baseline: camera paths when --cpu-seconds is 0 (both 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--batch-samples", type=int, default=0)
     ap.add_argument("--no-calibrate", action="store_true")
@@ -223,8 +229,8 @@ def main():
                                    "film": st.ms_film / args.steps},
             "roofline": roofline,
         }
-        if world == 1 and args.cpu_paths > 0:
-            out["cpu_baseline"] = cpu_baseline(scene, rs, args.cpu_threads, args.cpu_paths)
+        if world == 1 and (args.cpu_paths > 0 or args.cpu_seconds > 0):
+            out["cpu_baseline"] = cpu_baseline(scene, rs, args.cpu_threads, args.cpu_paths, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
