@@ -109,7 +109,8 @@ def hip_lib():
     """librrt_hip.so.  Raises RrtError when it has not been built: there is no other compute path."""
     global _hip
     if _hip is None:
-        path = os.path.join(HERE, "librrt_hip.so")
+        # RRT_HIP_LIB selects another build of the same library (A/B timing of kernel variants)
+        path = os.environ.get("RRT_HIP_LIB") or os.path.join(HERE, "librrt_hip.so")
         if not os.path.exists(path):
             raise RrtError("librrt_hip.so is missing: run `python rust-raytracer_amd/build.py`")
         lib = C.CDLL(path, mode=C.RTLD_GLOBAL)

@@ -25,6 +25,9 @@ thread_local std::string g_create_error;
 
 constexpr uint32_t kDefaultMaxSlots = 32u << 20;  // paths kept in flight per batch
 constexpr int kBlock = 256;
+constexpr uint32_t kQueueGridBlocks = 8192;  // 32 blocks per CU: enough to balance uneven traversal times
+
+inline uint32_t grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 struct EventPair {
   hipEvent_t begin, end;
@@ -154,11 +157,12 @@ int ensure_state(rrt_ctx* ctx, uint32_t n_slots, uint32_t depth, bool need_mis) 
     for (float4** arr : mis_arrays)
       if ((rc = state_alloc(ctx, arr, n_slots)) != RRT_OK) return rc;
   }
-  if ((rc = state_alloc(ctx, &a.queue[0], n_slots)) != RRT_OK) return rc;
-  if ((rc = state_alloc(ctx, &a.queue[1], n_slots)) != RRT_OK) return rc;
-  if ((rc = state_alloc(ctx, &a.sh_queue, n_slots)) != RRT_OK) return rc;
-  if ((rc = state_alloc(ctx, &a.live_count, 2 * (size_t)depth + 2)) != RRT_OK) return rc;
-  a.sh_count = a.live_count + depth + 1;
+  // queues: kSegments fixed-size segments, each able to hold everything its blocks can produce
+  const size_t seg_cap = (size_t)((grid_for(n_slots) + kSegments - 1) / kSegments) * kBlock;
+  if ((rc = state_alloc(ctx, &a.q_shade, seg_cap * kSegments)) != RRT_OK) return rc;
+  if ((rc = state_alloc(ctx, &a.q_extend, seg_cap * kSegments)) != RRT_OK) return rc;
+  if ((rc = state_alloc(ctx, &a.q_shadow, seg_cap * kSegments)) != RRT_OK) return rc;
+  if ((rc = state_alloc(ctx, &a.counters, (size_t)counter_rows(depth) * kSegments * kCounterStride)) != RRT_OK) return rc;
   ctx->state_slots = n_slots;
   ctx->state_depth = depth;
   ctx->state_has_mis = need_mis;
@@ -275,24 +279,28 @@ int collect_timing(rrt_ctx* ctx) {
   return RRT_OK;
 }
 
-inline uint32_t grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
-
 // One batch: tiles [tile_begin, tile_begin + n_tiles) x samples [sample_begin, sample_begin + k).
-int launch_batch(rrt_ctx* ctx, RenderParams& p) {
+int launch_batch(rrt_ctx* ctx, RenderParams& p, uint64_t live_paths) {
   const uint32_t depth = p.depth_limit;
-  // the counter block was sized for the deepest render so far; lay this render's two arrays out in it
-  p.a.sh_count = p.a.live_count + depth + 1;
-  HIP_TRY(ctx, hipMemsetAsync(p.a.live_count, 0, sizeof(uint32_t) * (2 * (size_t)depth + 2), ctx->stream));
-  const uint32_t grid = grid_for(p.n_slots);
+  HIP_TRY(ctx, hipMemsetAsync(p.a.counters, 0, sizeof(uint32_t) * (size_t)counter_rows(depth) * kSegments * kCounterStride,
+                              ctx->stream));
+  const uint32_t grid_all = grid_for(p.n_slots);
+  p.a.seg_cap = ((grid_all + kSegments - 1) / kSegments) * kBlock;
+  // queue-driven kernels run on a fixed grid that walks its queue: a launch over a short queue
+  // (late bounces) then costs a few microseconds instead of one empty block per 256 slots
+  const uint32_t grid = std::min(grid_all, kQueueGridBlocks);
   int rc;
   if ((rc = record_begin(ctx, 0)) != RRT_OK) return rc;
-  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera);
+  if (ctx->count_traversal) hipLaunchKernelGGL(k_primary<true>, dim3(grid_all), dim3(kBlock), 0, ctx->stream, p, ctx->camera);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(grid_all), dim3(kBlock), 0, ctx->stream, p, ctx->camera);
   if ((rc = record_end(ctx)) != RRT_OK) return rc;
   for (uint32_t b = 0; b < depth; ++b) {
-    if ((rc = record_begin(ctx, 1)) != RRT_OK) return rc;
-    if (ctx->count_traversal) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
-    if ((rc = record_end(ctx)) != RRT_OK) return rc;
+    if (b > 0) {
+      if ((rc = record_begin(ctx, 1)) != RRT_OK) return rc;
+      if (ctx->count_traversal) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
+      else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
+      if ((rc = record_end(ctx)) != RRT_OK) return rc;
+    }
     if ((rc = record_begin(ctx, 2)) != RRT_OK) return rc;
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
     if ((rc = record_end(ctx)) != RRT_OK) return rc;
@@ -303,7 +311,7 @@ int launch_batch(rrt_ctx* ctx, RenderParams& p) {
   }
   if ((rc = record_begin(ctx, 4)) != RRT_OK) return rc;
   hipLaunchKernelGGL(k_film, dim3(grid_for(p.n_tiles * 64)), dim3(kBlock), 0, ctx->stream, p);
-  hipLaunchKernelGGL(k_batch_stats, dim3(1), dim3(64), 0, ctx->stream, p);
+  hipLaunchKernelGGL(k_batch_stats, dim3(1), dim3(64), 0, ctx->stream, p, (unsigned long long)live_paths);
   if ((rc = record_end(ctx)) != RRT_OK) return rc;
   HIP_TRY(ctx, hipGetLastError());
   return collect_timing(ctx);
@@ -644,11 +652,16 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
   for (uint64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_batch) {
     p.tile_begin = (uint32_t)t0;
     p.n_tiles = (uint32_t)std::min<uint64_t>(tiles_per_batch, total_tiles - t0);
+    uint64_t live_pixels = 0;  // pixels of these 8x8 tiles that lie inside the window
+    for (uint64_t t = t0; t < t0 + p.n_tiles; ++t) {
+      const uint32_t tx = (uint32_t)(t % tiles_x), ty = (uint32_t)(t / tiles_x);
+      live_pixels += (uint64_t)std::min(8u, win_w - tx * 8) * std::min(8u, win_h - ty * 8);
+    }
     for (uint32_t s0 = sample_begin; s0 < sample_end; s0 += k) {
       p.sample_begin = s0;
       p.n_samples = std::min(k, sample_end - s0);
       p.n_slots = p.n_tiles * 64 * p.n_samples;
-      if ((rc = launch_batch(ctx, p)) != RRT_OK) return rc;
+      if ((rc = launch_batch(ctx, p, live_pixels * p.n_samples)) != RRT_OK) return rc;
     }
   }
   return RRT_OK;

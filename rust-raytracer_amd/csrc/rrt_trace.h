@@ -13,8 +13,33 @@ struct Hit {
   float t, u, v;
 };
 
-constexpr int kStackSize = 64;
 constexpr float kTriTMax = 1000.0f;  // objects/triangle.rs:164-171
+
+// Traversal stack: the first kLdsDepth entries of every lane live in LDS, laid out
+// [entry][thread] so that the 64 lanes of a wave hit 64 consecutive words (no bank
+// conflicts); deeper entries -- rare -- spill to a per-lane array in scratch memory.
+constexpr int kTraceBlock = 256;   // threads per block of every kernel that traverses
+#ifndef RRT_LDS_STACK_DEPTH
+#define RRT_LDS_STACK_DEPTH 0  // measured: 0 (all in scratch) beats 12, 16 and 24 -- LDS costs a wave of occupancy
+#endif
+constexpr int kLdsDepth = RRT_LDS_STACK_DEPTH;
+constexpr int kSpillDepth = 96 - kLdsDepth;  // 96 entries in all: deeper than any tree the builder makes (SAH depth <= 40 + median levels)
+#define RRT_DECLARE_TRACE_STACK() __shared__ int rrt_trace_stack[(rrt::kLdsDepth > 0 ? rrt::kLdsDepth : 1) * rrt::kTraceBlock]
+
+struct TraceStack {
+  int* lds;  // this thread's column: entry e at lds[e * kTraceBlock]
+  int spill[kSpillDepth];
+  int sp;
+  RRT_DEV void push(int v) {
+    if (sp < kLdsDepth) lds[sp * kTraceBlock] = v;
+    else if (sp < kLdsDepth + kSpillDepth) spill[sp - kLdsDepth] = v;
+    ++sp;
+  }
+  RRT_DEV int pop() {
+    --sp;
+    return sp < kLdsDepth ? lds[sp * kTraceBlock] : spill[min(sp - kLdsDepth, kSpillDepth - 1)];
+  }
+};
 
 struct RayPre {
   V3 o, d, inv, ood;  // ood = o * inv
@@ -77,9 +102,10 @@ struct TraceCounters {
 // ray leaves), or -1.  Returns true when something was hit.
 template <bool ANY, bool COUNT>
 RRT_DEV bool traverse_tris(const BvhNode* __restrict__ nodes, const TriIsect* __restrict__ tris, const RayPre& r,
-                           float tmin, float tmax, int skip, Hit* hit, TraceCounters* ctr) {
-  int stack[kStackSize];
-  int sp = 0;
+                           float tmin, float tmax, int skip, Hit* hit, TraceCounters* ctr, int* lds_stack) {
+  TraceStack stack;
+  stack.lds = lds_stack + threadIdx.x;
+  stack.sp = 0;
   int cur = 0;
   bool found = false;
   const int kDone = 0x7fffffff;
@@ -96,14 +122,14 @@ RRT_DEV bool traverse_tris(const BvhNode* __restrict__ nodes, const TriIsect* __
         const bool left_first = tl <= tr;
         const int nearc = left_first ? n3.x : n3.y;
         const int farc = left_first ? n3.y : n3.x;
-        if (sp < kStackSize) stack[sp++] = farc;
+        stack.push(farc);
         cur = nearc;
       } else if (hl) {
         cur = n3.x;
       } else if (hr) {
         cur = n3.y;
       } else {
-        cur = sp > 0 ? stack[--sp] : kDone;
+        cur = stack.sp > 0 ? stack.pop() : kDone;
       }
     }
     if (cur == kDone) break;
@@ -124,7 +150,7 @@ RRT_DEV bool traverse_tris(const BvhNode* __restrict__ nodes, const TriIsect* __
         found = true;
       }
     }
-    cur = sp > 0 ? stack[--sp] : kDone;
+    cur = stack.sp > 0 ? stack.pop() : kDone;
   }
   return found;
 }
@@ -223,13 +249,13 @@ RRT_DEV bool intersect_others(const SceneTables* __restrict__ sc, const RayPre& 
 // check_intersect_scene
 template <bool COUNT>
 RRT_DEV Hit closest_hit(const BvhNode* __restrict__ nodes, const TriIsect* __restrict__ tris,
-                        const SceneTables* __restrict__ sc, V3 o, V3 d, TraceCounters* ctr) {
+                        const SceneTables* __restrict__ sc, V3 o, V3 d, TraceCounters* ctr, int* lds_stack) {
   Hit hit;
   hit.prim = -1;
   hit.t = INFINITY;
   hit.u = hit.v = 0.0f;
   const RayPre r = prepare_ray(o, d);
-  if (sc->n_tris > 0) traverse_tris<false, COUNT>(nodes, tris, r, 0.0f, kTriTMax, -1, &hit, ctr);
+  if (sc->n_tris > 0) traverse_tris<false, COUNT>(nodes, tris, r, 0.0f, kTriTMax, -1, &hit, ctr, lds_stack);
   if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, hit.t, -1, -1, &hit);
   return hit;
 }
@@ -238,13 +264,13 @@ RRT_DEV Hit closest_hit(const BvhNode* __restrict__ nodes, const TriIsect* __res
 template <bool COUNT>
 RRT_DEV bool any_hit(const BvhNode* __restrict__ nodes, const TriIsect* __restrict__ tris,
                      const SceneTables* __restrict__ sc, V3 o, V3 d, float tmax, int skip_a, int skip_b,
-                     TraceCounters* ctr) {
+                     TraceCounters* ctr, int* lds_stack) {
   const RayPre r = prepare_ray(o, d);
   Hit hit;
   // only skip_a can name a triangle (the surface a ray leaves); skip_b names a light's quad
   if (sc->n_tris > 0 &&
       traverse_tris<true, COUNT>(nodes, tris, r, 0.0f, fminf(tmax, kTriTMax), skip_a < sc->n_tris ? skip_a : -1, &hit,
-                                 ctr))
+                                 ctr, lds_stack))
     return true;
   if (sc->n_rects + sc->n_planes + sc->n_spheres > 0 && intersect_others<true>(sc, r, tmax, skip_a, skip_b, &hit))
     return true;
