@@ -25,7 +25,8 @@ thread_local std::string g_create_error;
 
 constexpr uint32_t kDefaultMaxSlots = 32u << 20;  // paths kept in flight per batch
 constexpr int kBlock = 256;
-constexpr uint32_t kQueueGridBlocks = 8192;  // 32 blocks per CU: enough to balance uneven traversal times
+constexpr uint32_t kQueueGridBlocks = 8192;  // 32 blocks per CU for the kernels that walk a queue chunk by chunk
+constexpr uint32_t kTraceGridBlocks = 2048;  // 8 blocks = 32 waves per CU: at least what a CU can hold of the traversal kernels
 
 inline uint32_t grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
@@ -69,6 +70,8 @@ struct rrt_ctx {
   bool state_has_mis = false;
 
   DeviceStats* d_stats = nullptr;
+  uint32_t* d_work = nullptr;     // job cursor of the rrt_intersect / rrt_occluded launches
+  uint32_t* h_pending = nullptr;  // pinned: the two queue-length rows read back between iterations
 
   // options
   bool timing = false;
@@ -149,7 +152,7 @@ int ensure_state(rrt_ctx* ctx, uint32_t n_slots, uint32_t depth, bool need_mis) 
   free_state(ctx);
   PathArrays& a = ctx->arrays;
   int rc;
-  float4** main_arrays[] = {&a.ray_o, &a.ray_d, &a.beta, &a.radiance, &a.hit, &a.sh_o, &a.sh_d, &a.sh_c};
+  float4** main_arrays[] = {&a.ray_o, &a.ray_d, &a.beta, &a.radiance, &a.accum, &a.hit, &a.sh_o, &a.sh_d, &a.sh_c};
   for (float4** arr : main_arrays)
     if ((rc = state_alloc(ctx, arr, n_slots)) != RRT_OK) return rc;
   if (need_mis) {
@@ -157,12 +160,17 @@ int ensure_state(rrt_ctx* ctx, uint32_t n_slots, uint32_t depth, bool need_mis) 
     for (float4** arr : mis_arrays)
       if ((rc = state_alloc(ctx, arr, n_slots)) != RRT_OK) return rc;
   }
-  // queues: kSegments fixed-size segments, each able to hold everything its blocks can produce
-  const size_t seg_cap = (size_t)((grid_for(n_slots) + kSegments - 1) / kSegments) * kBlock;
-  if ((rc = state_alloc(ctx, &a.q_shade, seg_cap * kSegments)) != RRT_OK) return rc;
-  if ((rc = state_alloc(ctx, &a.q_extend, seg_cap * kSegments)) != RRT_OK) return rc;
-  if ((rc = state_alloc(ctx, &a.q_shadow, seg_cap * kSegments)) != RRT_OK) return rc;
-  if ((rc = state_alloc(ctx, &a.counters, (size_t)counter_rows(depth) * kSegments * kCounterStride)) != RRT_OK) return rc;
+  // queues: kSegments fixed-size segments.  A segment takes what the chunks c = segment (mod
+  // kSegments) of a launch produce; the start queue is fed by two launches (extend and shade).
+  // (extend hands in results per index block of at most 1024 jobs, shade per chunk of 256.)
+  a.seg_cap = 2 * ((n_slots + kSegments - 1) / kSegments) + n_slots / 2048 + 4096;
+  const size_t queue_words = (size_t)a.seg_cap * kSegments;
+  uint32_t** queues[] = {&a.q_start[0], &a.q_start[1], &a.q_cont[0], &a.q_cont[1], &a.q_camera, &a.q_shade, &a.q_shadow};
+  for (uint32_t** q : queues)
+    if ((rc = state_alloc(ctx, q, queue_words)) != RRT_OK) return rc;
+  if ((rc = state_alloc(ctx, &a.counters, (size_t)kCounterRows * kSegments * kCounterStride)) != RRT_OK) return rc;
+  if (!ctx->h_pending)
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_pending, sizeof(uint32_t) * 2 * kSegments * kCounterStride, hipHostMallocDefault));
   ctx->state_slots = n_slots;
   ctx->state_depth = depth;
   ctx->state_has_mis = need_mis;
@@ -279,39 +287,63 @@ int collect_timing(rrt_ctx* ctx) {
   return RRT_OK;
 }
 
-// One batch: tiles [tile_begin, tile_begin + n_tiles) x samples [sample_begin, sample_begin + k).
-int launch_batch(rrt_ctx* ctx, RenderParams& p, uint64_t live_paths) {
-  const uint32_t depth = p.depth_limit;
-  HIP_TRY(ctx, hipMemsetAsync(p.a.counters, 0, sizeof(uint32_t) * (size_t)counter_rows(depth) * kSegments * kCounterStride,
-                              ctx->stream));
+// One pass: every sample of [sample_begin, sample_end) for the pixels of tiles
+// [tile_begin, tile_begin + n_tiles).  Iterations of extend / shade / connect run until no slot has
+// a path or a sample left; how many that takes depends on the paths, so the host reads the two
+// queue lengths back every few iterations (a 16 KB copy and one stream synchronisation).
+int launch_pass(rrt_ctx* ctx, RenderParams& p) {
+  const size_t row_words = (size_t)kSegments * kCounterStride, row_bytes = sizeof(uint32_t) * row_words;
+  HIP_TRY(ctx, hipMemsetAsync(p.a.counters, 0, row_bytes * kCounterRows, ctx->stream));
   const uint32_t grid_all = grid_for(p.n_slots);
-  p.a.seg_cap = ((grid_all + kSegments - 1) / kSegments) * kBlock;
   // queue-driven kernels run on a fixed grid that walks its queue: a launch over a short queue
-  // (late bounces) then costs a few microseconds instead of one empty block per 256 slots
-  const uint32_t grid = std::min(grid_all, kQueueGridBlocks);
+  // then costs a few microseconds instead of one empty block per 256 slots
+  const uint32_t grid = std::min(grid_all + 1, kQueueGridBlocks);
+  // traversal kernels: enough blocks to fill every CU; their waves take jobs from a cursor
+  const uint32_t trace_grid = std::min(grid_all + 1, kTraceGridBlocks);
   int rc;
   if ((rc = record_begin(ctx, 0)) != RRT_OK) return rc;
-  if (ctx->count_traversal) hipLaunchKernelGGL(k_primary<true>, dim3(grid_all), dim3(kBlock), 0, ctx->stream, p, ctx->camera);
-  else hipLaunchKernelGGL(k_primary<false>, dim3(grid_all), dim3(kBlock), 0, ctx->stream, p, ctx->camera);
+  hipLaunchKernelGGL(k_init, dim3(grid_all), dim3(kBlock), 0, ctx->stream, p);
   if ((rc = record_end(ctx)) != RRT_OK) return rc;
-  for (uint32_t b = 0; b < depth; ++b) {
-    if (b > 0) {
+
+  const uint32_t per_slot = (p.sample_end - p.sample_begin + p.n_samples - 1) / p.n_samples;
+  // a slot needs at least one iteration per sample plus one to retire, at most depth_limit per sample
+  const uint64_t max_iterations = (uint64_t)per_slot * p.depth_limit + 2;
+  uint64_t it = 0;
+  uint32_t burst = per_slot + 1;
+  for (;;) {
+    for (uint32_t j = 0; j < burst; ++j, ++it) {
+      const uint32_t parity = (uint32_t)(it & 1), next = parity ^ 1u;
+      // camera, shade, shadow and the two queues of the other parity start this iteration empty
+      HIP_TRY(ctx, hipMemsetAsync(p.a.counters + row_words * 2 * next, 0, row_bytes * kRowsPerIteration, ctx->stream));
+      if ((rc = record_begin(ctx, 0)) != RRT_OK) return rc;
+      hipLaunchKernelGGL(k_start, dim3(grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, parity);
+      if ((rc = record_end(ctx)) != RRT_OK) return rc;
       if ((rc = record_begin(ctx, 1)) != RRT_OK) return rc;
-      if (ctx->count_traversal) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
-      else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
+      if (ctx->count_traversal) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, parity);
+      else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, parity);
+      if ((rc = record_end(ctx)) != RRT_OK) return rc;
+      if ((rc = record_begin(ctx, 2)) != RRT_OK) return rc;
+      hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, ctx->stream, p, parity);
+      if ((rc = record_end(ctx)) != RRT_OK) return rc;
+      if ((rc = record_begin(ctx, 3)) != RRT_OK) return rc;
+      if (ctx->count_traversal) hipLaunchKernelGGL(k_connect<true>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p);
+      else hipLaunchKernelGGL(k_connect<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p);
       if ((rc = record_end(ctx)) != RRT_OK) return rc;
     }
-    if ((rc = record_begin(ctx, 2)) != RRT_OK) return rc;
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
-    if ((rc = record_end(ctx)) != RRT_OK) return rc;
-    if ((rc = record_begin(ctx, 3)) != RRT_OK) return rc;
-    if (ctx->count_traversal) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
-    else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, p, b);
-    if ((rc = record_end(ctx)) != RRT_OK) return rc;
+    // rows start/cont of the parity the next iteration would read sit next to each other
+    const uint32_t parity = (uint32_t)(it & 1);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pending, p.a.counters + row_words * (parity ? kRowStart1 : kRowStart0), row_bytes * 2,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t pending = 0;
+    for (int i = 0; i < 2 * kSegments; ++i) pending += ctx->h_pending[(size_t)i * kCounterStride];
+    if (pending == 0) break;
+    if (it >= max_iterations) return fail(ctx, RRT_E_DEVICE, "path queues did not drain");
+    burst = (uint32_t)std::min<uint64_t>(4, max_iterations - it);
   }
   if ((rc = record_begin(ctx, 4)) != RRT_OK) return rc;
   hipLaunchKernelGGL(k_film, dim3(grid_for(p.n_tiles * 64)), dim3(kBlock), 0, ctx->stream, p);
-  hipLaunchKernelGGL(k_batch_stats, dim3(1), dim3(64), 0, ctx->stream, p, (unsigned long long)live_paths);
+  hipLaunchKernelGGL(k_pass_stats, dim3(1), dim3(64), 0, ctx->stream, p);
   if ((rc = record_end(ctx)) != RRT_OK) return rc;
   HIP_TRY(ctx, hipGetLastError());
   return collect_timing(ctx);
@@ -348,6 +380,7 @@ rrt_ctx* rrt_create(int device) {
   }
   ctx->device = device;
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&ctx->d_stats, sizeof(DeviceStats)) != hipSuccess ||
+      hipMalloc((void**)&ctx->d_work, sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess) {
     g_create_error = "cannot initialise device " + std::to_string(device);
     delete ctx;
@@ -364,6 +397,8 @@ void rrt_destroy(rrt_ctx* ctx) {
   free_state(ctx);
   if (ctx->film_owned) (void)hipFree(ctx->d_film);
   (void)hipFree(ctx->d_stats);
+  (void)hipFree(ctx->d_work);
+  if (ctx->h_pending) (void)hipHostFree(ctx->h_pending);
   for (EventPair& e : ctx->events) {
     (void)hipEventDestroy(e.begin);
     (void)hipEventDestroy(e.end);
@@ -652,17 +687,11 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
   for (uint64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_batch) {
     p.tile_begin = (uint32_t)t0;
     p.n_tiles = (uint32_t)std::min<uint64_t>(tiles_per_batch, total_tiles - t0);
-    uint64_t live_pixels = 0;  // pixels of these 8x8 tiles that lie inside the window
-    for (uint64_t t = t0; t < t0 + p.n_tiles; ++t) {
-      const uint32_t tx = (uint32_t)(t % tiles_x), ty = (uint32_t)(t / tiles_x);
-      live_pixels += (uint64_t)std::min(8u, win_w - tx * 8) * std::min(8u, win_h - ty * 8);
-    }
-    for (uint32_t s0 = sample_begin; s0 < sample_end; s0 += k) {
-      p.sample_begin = s0;
-      p.n_samples = std::min(k, sample_end - s0);
-      p.n_slots = p.n_tiles * 64 * p.n_samples;
-      if ((rc = launch_batch(ctx, p, live_pixels * p.n_samples)) != RRT_OK) return rc;
-    }
+    p.sample_begin = sample_begin;
+    p.sample_end = sample_end;
+    p.n_samples = k;
+    p.n_slots = p.n_tiles * 64 * k;
+    if ((rc = launch_pass(ctx, p)) != RRT_OK) return rc;
   }
   return RRT_OK;
 }
@@ -692,9 +721,10 @@ int rrt_intersect(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_t* prim_
   if (rc == RRT_OK) {
     e = hipMemcpyAsync(d_rays, org_dir, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_intersect, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes, ctx->d_tris,
-                         ctx->d_scene, d_rays, n, d_prim, d_t);
-      e = hipGetLastError();
+      e = hipMemsetAsync(ctx->d_work, 0, sizeof(uint32_t), ctx->stream);
+      hipLaunchKernelGGL(k_intersect, dim3(std::min(grid_for(n), kTraceGridBlocks)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes,
+                         ctx->d_tris, ctx->d_scene, d_rays, n, d_prim, d_t, ctx->d_work);
+      if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(prim_id, d_prim, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(t, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
@@ -723,9 +753,10 @@ int rrt_occluded(rrt_ctx* ctx, const float* org_dir_tmax, uint32_t n, uint8_t* h
   if (rc == RRT_OK) {
     e = hipMemcpyAsync(d_rays, org_dir_tmax, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_occluded, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes, ctx->d_tris,
-                         ctx->d_scene, d_rays, n, d_hit);
-      e = hipGetLastError();
+      e = hipMemsetAsync(ctx->d_work, 0, sizeof(uint32_t), ctx->stream);
+      hipLaunchKernelGGL(k_occluded, dim3(std::min(grid_for(n), kTraceGridBlocks)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes,
+                         ctx->d_tris, ctx->d_scene, d_rays, n, d_hit, ctx->d_work);
+      if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(hit, d_hit, (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -1,28 +1,33 @@
-// The wavefront path tracer: one kernel per stage of trace() (src/tracer.rs:24-139),
-// run once per bounce over queues of live path slots.
+// The streaming wavefront path tracer: the stages of trace() (src/tracer.rs:24-139) as kernels
+// that run once per iteration over queues of path slots.
 //
-//   primary  bounce 0 in one kernel: get_camera_sample + Camera::generate_ray (src/sampler.rs:76-83,
-//            src/camera.rs:103-125), check_intersect_scene (src/renderer.rs:213-249) and, for rays that
-//            escape, the environment pickup (src/tracer.rs:50-53).  Only paths that hit a surface get
-//            their state written and enter the queues.
+//   start    slots whose path has ended: a ray that escaped picks up the environment if it was a
+//            camera ray or followed a specular bounce (src/tracer.rs:44-63); the finished radiance
+//            is banked; the slot takes its next sample and generates the camera ray
+//            (src/sampler.rs:76-83, src/camera.rs:103-125)
+//   extend   check_intersect_scene (src/renderer.rs:213-249) for camera and continuation rays.
+//            Nothing else lives in this kernel: its register count decides how many rays a CU
+//            keeps in flight.
 //   shade    the body of the bounce loop for paths that hit something: the material's lobes,
 //            uniform_sample_light + estimate_direct up to (not including) their visibility rays, the
 //            continuation sample, throughput, Russian roulette (src/tracer.rs:70-130, 141-283)
 //   connect  the visibility rays estimate_direct asked for (src/renderer.rs:277-295 and the
 //            closest-hit ray of src/tracer.rs:252) and the radiance clamp (src/tracer.rs:116-120)
-//   extend   check_intersect_scene for the continuation rays of bounce >= 1; an escaping ray picks
-//            up the environment if the previous bounce was specular (src/tracer.rs:44-63) and ends
 //   film     Film::write_bucket_pixels with filter none (src/film.rs:157-167): per-pixel sums
 //
-// A path lives in one slot of the structure-of-arrays state for its whole life; queues hold slot
-// numbers and are rebuilt by every kernel with a wave ballot + prefix count + one atomic per wave,
-// so shade only ever sees surface hits and later bounces run with full waves.
+// A slot belongs to one pixel for the whole render and works through that pixel's samples
+// k, k + K, k + 2K, ... one path after the other; when a path ends the slot starts the next one in
+// the following iteration, so every launch stays as wide as the pool until the samples run out.
+// (Running a batch of paths to completion instead leaves a dozen launches per batch that wait on
+// the few longest paths with the machine nearly empty: that was 2/3 of the frame time.)
+// The result does not depend on the schedule: a path is a function of (seed, pixel, sample), a
+// slot adds its finished paths in sample order, and film adds a pixel's slots in slot order.
 //
-// Queues are split into kSegments segments with a counter each.  One counter for a whole launch
-// would take one returning atomic per wave on ONE address -- about 11 ns each, 2 million of them for
-// a 33 M-path batch -- and that, not the ray tracing, set the kernel time.  Block b appends to
-// segment b % kSegments; a segment can never receive more than its blocks have threads, so
-// segments are fixed-size regions of one array and need no overflow handling.
+// Queues hold slot numbers and are rebuilt by every kernel with a wave ballot + prefix count + one
+// atomic per wave.  They are split into kSegments segments with a counter each: one counter for a
+// whole launch would take one returning atomic per wave on ONE address -- about 11 ns each, 2
+// million of them for a 33 M-slot launch -- and that, not the ray tracing, would set the kernel
+// time.  Chunk c of a launch appends to segment c % kSegments.
 #pragma once
 #include "rrt_device.h"
 #include "rrt_math.h"
@@ -40,12 +45,31 @@ constexpr uint32_t kHasLightRay = 1u, kHasMisRay = 2u, kClamp = 4u;
 
 constexpr int kSegments = 64;        // queue segments = lanes of a wave (one lane scans one counter)
 constexpr int kCounterStride = 32;   // words between counters: each sits in a 128-byte line of its own
+// Flags of a start-queue entry (slot numbers stay below 2^30).
+constexpr uint32_t kFresh = 0x80000000u;    // the slot has no finished path to bank yet
+constexpr uint32_t kEscaped = 0x40000000u;  // the path ended because its ray left the scene
+constexpr uint32_t kSlotMask = 0x3fffffffu;
+
+// Counter rows.  The queues written during iteration i for iteration i + 1 use parity (i + 1) & 1;
+// rows [2 * parity, 2 * parity + 7) are exactly the ones to zero before iteration i starts.
+// A work row holds one word: the cursor from which a traversal kernel's waves take their jobs.
+enum : uint32_t {
+  kRowStart0 = 0, kRowCont0 = 1, kRowCamera = 2, kRowShade = 3, kRowShadow = 4, kRowWorkExtend = 5, kRowWorkConnect = 6,
+  kRowStart1 = 7, kRowCont1 = 8,
+  kRowsPerIteration = 7,
+  // running totals over the whole pass (never reset between iterations)
+  kRowPaths = 9, kRowContRays = 10, kRowBounces = 11, kRowLightRays = 12, kRowMisRays = 13,
+  kCounterRows = 14
+};
+RRT_DEV uint32_t row_start(uint32_t parity) { return parity ? kRowStart1 : kRowStart0; }
+RRT_DEV uint32_t row_cont(uint32_t parity) { return parity ? kRowCont1 : kRowCont0; }
 
 struct PathArrays {
-  float4* ray_o;      // xyz origin
-  float4* ray_d;      // xyz direction, w = bit 0: previous bounce sampled a specular lobe
-  float4* beta;       // path throughput (`contribution` in the reference)
-  float4* radiance;   // accumulated L
+  float4* ray_o;      // xyz origin, w = sample index of the slot's current path (uint bits)
+  float4* ray_d;      // xyz direction, w = bounce << 1 | previous bounce sampled a specular lobe
+  float4* beta;       // path throughput (`contribution` in the reference); 1 at bounce 0 and not stored
+  float4* radiance;   // L of the current path; written by shade at bounce 0
+  float4* accum;      // sum of the slot's finished paths, w = their number
   float4* hit;        // prim (int bits), t, u, v
   float4* sh_o;       // light-sample visibility ray: origin xyz, w = max distance
   float4* sh_d;       // direction xyz, w = object code of the sampled light's quad (int bits)
@@ -53,11 +77,13 @@ struct PathArrays {
   float4* mis_o;      // escape ray of the BSDF-sampling estimator (environment light only)
   float4* mis_d;
   float4* mis_c;
-  uint32_t* q_shade;    // slots whose ray hit a surface this bounce
-  uint32_t* q_extend;   // slots with a continuation ray for the next bounce
-  uint32_t* q_shadow;   // slots with visibility work this bounce
-  uint32_t* counters;   // rows of kSegments counters: see the row_* helpers
-  uint32_t seg_cap;     // capacity of one queue segment
+  uint32_t* q_start[2];  // slots whose path has ended (or not begun), with entry flags
+  uint32_t* q_cont[2];   // slots with a continuation ray
+  uint32_t* q_camera;    // slots with a new camera ray
+  uint32_t* q_shade;     // slots whose ray hit a surface this iteration
+  uint32_t* q_shadow;    // slots with visibility work this iteration
+  uint32_t* counters;    // kCounterRows rows of kSegments counters
+  uint32_t seg_cap;      // capacity of one queue segment
 };
 
 struct RenderParams {
@@ -74,31 +100,23 @@ struct RenderParams {
   uint32_t width, height;           // film size
   uint32_t win_x0, win_y0, win_w, win_h;  // render window
   uint32_t tiles_x;                 // 8x8 pixel tiles per window row
-  uint32_t tile_begin, n_tiles;     // tiles of this batch
-  uint32_t sample_begin, n_samples; // samples of this batch (K)
-  uint32_t n_slots;                 // n_tiles * 64 * n_samples
+  uint32_t tile_begin, n_tiles;     // tiles of this pass
+  uint32_t sample_begin, sample_end;
+  uint32_t n_samples;               // K: slots per pixel
+  uint32_t n_slots;                 // n_tiles * 64 * K
   uint32_t depth_limit;
   float clamp;
 };
-
-// Counter rows of one batch: shade[b], extend[b] (b = 1..depth), shadow[b], and the number of
-// environment-light escape rays mis[b].
-RRT_DEV uint32_t row_shade(const RenderParams& p, uint32_t b) { return b; }
-RRT_DEV uint32_t row_extend(const RenderParams& p, uint32_t b) { return p.depth_limit + b; }
-RRT_DEV uint32_t row_shadow(const RenderParams& p, uint32_t b) { return 2 * p.depth_limit + 1 + b; }
-RRT_DEV uint32_t row_mis(const RenderParams& p, uint32_t b) { return 3 * p.depth_limit + 1 + b; }
-RRT_DEV uint32_t row_light(const RenderParams& p, uint32_t b) { return 4 * p.depth_limit + 1 + b; }
-inline uint32_t counter_rows(uint32_t depth) { return 5 * depth + 1; }
 
 RRT_DEV uint32_t* counter_at(uint32_t* counters, uint32_t row, uint32_t seg) {
   return counters + ((size_t)row * kSegments + seg) * kCounterStride;
 }
 
-// slot -> pixel, sample.  Consecutive slots are the samples of one pixel;
+// slot -> pixel and the slot's lane k among the pixel's K slots.  Consecutive slots share a pixel;
 // consecutive pixels walk an 8x8 tile.
-RRT_DEV bool slot_pixel(const RenderParams& p, uint32_t slot, uint32_t* x, uint32_t* y, uint32_t* sample) {
+RRT_DEV bool slot_pixel(const RenderParams& p, uint32_t slot, uint32_t* x, uint32_t* y, uint32_t* k) {
   const uint32_t pix = slot / p.n_samples;
-  *sample = p.sample_begin + slot % p.n_samples;
+  *k = slot % p.n_samples;
   const uint32_t tile = p.tile_begin + pix / 64, in = pix % 64;
   const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
   const uint32_t lx = tx * 8 + (in & 7), ly = ty * 8 + (in >> 3);
@@ -107,10 +125,12 @@ RRT_DEV bool slot_pixel(const RenderParams& p, uint32_t slot, uint32_t* x, uint3
   return lx < p.win_w && ly < p.win_h;
 }
 
-// Appends `slot` of every lane with `keep` to a queue: one atomic per wave, on the counter of
-// segment chunk % kSegments, where `chunk` numbers the 256 work items this block is working on.
+// Appends `entry` of every lane with `keep` to a queue: one atomic per wave, on the counter of
+// segment chunk % kSegments, where `chunk` numbers the block of work items the lanes are working
+// on (the same for all lanes that push together).  A segment can overflow only if the chunks that
+// map to it produce more than seg_cap entries; callers size seg_cap from their chunk sizes.
 RRT_DEV void queue_push(const RenderParams& p, uint32_t* __restrict__ queue, uint32_t row, uint32_t chunk, bool keep,
-                        uint32_t slot) {
+                        uint32_t entry) {
   const unsigned long long mask = __ballot(keep);
   if (mask == 0) return;
   const int lane = threadIdx.x & 63;
@@ -119,7 +139,7 @@ RRT_DEV void queue_push(const RenderParams& p, uint32_t* __restrict__ queue, uin
   uint32_t base = 0;
   if (lane == leader) base = atomicAdd(counter_at(p.a.counters, row, seg), (uint32_t)__popcll(mask));
   base = __shfl(base, leader);
-  if (keep) queue[(size_t)seg * p.a.seg_cap + base + __popcll(mask & ((1ull << lane) - 1ull))] = slot;
+  if (keep) queue[(size_t)seg * p.a.seg_cap + base + __popcll(mask & ((1ull << lane) - 1ull))] = entry;
 }
 
 // Adds the number of lanes with `pred` to a counter row (no queue behind it).
@@ -132,7 +152,7 @@ RRT_DEV void counter_add(const RenderParams& p, uint32_t row, uint32_t chunk, bo
 
 // Consumer side.  queue_scan: the block's first wave scans the row's kSegments counters into LDS
 // (all threads of the block must call it: it synchronises) and returns the queue length.
-// queue_item: the slot stored as item i, found by a search over the scanned counters.
+// queue_item: the entry stored as item i, found by a search over the scanned counters.
 RRT_DEV uint32_t queue_scan(const RenderParams& p, uint32_t row, uint32_t* prefix /* LDS, kSegments + 1 words */) {
   if (threadIdx.x < kSegments) {
     uint32_t incl = *counter_at(p.a.counters, row, threadIdx.x);
@@ -194,93 +214,156 @@ RRT_DEV void camera_ray(const CameraParams& cam, uint32_t x, uint32_t y, const R
                       (float)w[8] * d.x + (float)w[9] * d.y + (float)w[10] * d.z));
 }
 
-// ---------------------------------------------------------------- primary (bounce 0)
-template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_primary(RenderParams p, CameraParams cam) {
-  RRT_DECLARE_TRACE_STACK();
+// ---------------------------------------------------------------- init
+// Every slot of a pixel inside the window enters the first start queue.
+__global__ void __launch_bounds__(256) k_init(RenderParams p) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  bool hit_surface = false;
-  TraceCounters ctr = {0, 0};
+  bool live = false;
   if (slot < p.n_slots) {
-    uint32_t x, y, sample;
-    if (slot_pixel(p, slot, &x, &y, &sample)) {
-      const Rng4 r = rng_block(p.seed, y * p.width + x, sample, 0);
-      V3 org, dir;
-      camera_ray(cam, x, y, r, &org, &dir);
-      const Hit h = closest_hit<COUNT>(p.nodes, p.tris, p.scene, org, dir, &ctr, rrt_trace_stack);
-      if (h.prim < 0) {
-        // the camera ray escapes: it sees the lights' environment term and the path is over
-        p.a.radiance[slot] = f4(escape_radiance(p.scene, p.env, dir), 0.0f);
-      } else {
-        hit_surface = true;
-        p.a.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        p.a.ray_o[slot] = f4(org, 0.0f);
-        p.a.ray_d[slot] = f4(dir, __uint_as_float(0u));
-        p.a.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        p.a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
-      }
-    }
+    uint32_t x, y, k;
+    live = slot_pixel(p, slot, &x, &y, &k);
+    p.a.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
-  queue_push(p, p.a.q_shade, row_shade(p, 0), blockIdx.x, hit_surface, slot);
-  flush_counters<COUNT>(p.stats, ctr);
+  queue_push(p, p.a.q_start[0], row_start(0), blockIdx.x, live, slot | kFresh);
 }
 
-// ---------------------------------------------------------------- extend (bounce >= 1)
-template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_extend(RenderParams p, uint32_t bounce) {
-  RRT_DECLARE_TRACE_STACK();
+// ---------------------------------------------------------------- start
+__global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam, uint32_t parity) {
   __shared__ uint32_t prefix[kSegments + 1];
-  const uint32_t n = queue_scan(p, row_extend(p, bounce), prefix);
-  TraceCounters ctr = {0, 0};
-  // a fixed grid walks the queue in chunks of one block's worth of rays
-  for (uint32_t chunk = blockIdx.x; chunk * kTraceBlock < n; chunk += gridDim.x) {
-  const uint32_t i = chunk * kTraceBlock + threadIdx.x;
-  uint32_t slot = 0;
-  bool hit_surface = false;
-  if (i < n) {
-    slot = queue_item(p, p.a.q_extend, prefix, i);
-    const float4 o = p.a.ray_o[slot], d = p.a.ray_d[slot];
-    const Hit h = closest_hit<COUNT>(p.nodes, p.tris, p.scene, mk(o), mk(d), &ctr, rrt_trace_stack);
-    if (h.prim < 0) {
-      // src/tracer.rs:44-63: an escaping ray sees the environment only after a specular bounce
-      if (__float_as_uint(d.w) & 1u) {
-        const V3 le = escape_radiance(p.scene, p.env, mk(d));
-        const float4 b = p.a.beta[slot];
-        float4 l4 = p.a.radiance[slot];
-        l4.x += b.x * le.x; l4.y += b.y * le.y; l4.z += b.z * le.z;
-        p.a.radiance[slot] = l4;
+  const uint32_t n = queue_scan(p, row_start(parity), prefix);
+  for (uint32_t chunk = blockIdx.x; chunk * 256 < n; chunk += gridDim.x) {
+    const uint32_t i = chunk * 256 + threadIdx.x;
+    uint32_t slot = 0;
+    bool started = false;
+    if (i < n) {
+      const uint32_t entry = queue_item(p, p.a.q_start[parity], prefix, i);
+      slot = entry & kSlotMask;
+      uint32_t x, y, k, sample;
+      slot_pixel(p, slot, &x, &y, &k);
+      if (entry & kFresh) {
+        sample = p.sample_begin + k;
+      } else {
+        float4 l4;
+        if (entry & kEscaped) {
+          const float4 d = p.a.ray_d[slot];
+          const uint32_t state = __float_as_uint(d.w);
+          if (state == 0u) {
+            // a camera ray that escapes sees the lights' environment term (src/tracer.rs:50-53)
+            l4 = f4(escape_radiance(p.scene, p.env, mk(d)), 0.0f);
+          } else {
+            l4 = p.a.radiance[slot];
+            if (state & 1u) {  // later rays only after a specular bounce (src/tracer.rs:44-63)
+              const V3 le = escape_radiance(p.scene, p.env, mk(d));
+              const float4 b = p.a.beta[slot];
+              l4.x += b.x * le.x; l4.y += b.y * le.y; l4.z += b.z * le.z;
+            }
+          }
+        } else {
+          l4 = p.a.radiance[slot];
+        }
+        float4 acc = p.a.accum[slot];
+        acc.x += l4.x; acc.y += l4.y; acc.z += l4.z; acc.w += 1.0f;
+        p.a.accum[slot] = acc;
+        sample = __float_as_uint(p.a.ray_o[slot].w) + p.n_samples;
       }
-    } else {
-      hit_surface = true;
-      p.a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+      if (sample < p.sample_end) {
+        const Rng4 r = rng_block(p.seed, y * p.width + x, sample, 0);
+        V3 org, dir;
+        camera_ray(cam, x, y, r, &org, &dir);
+        p.a.ray_o[slot] = f4(org, __uint_as_float(sample));
+        p.a.ray_d[slot] = f4(dir, __uint_as_float(0u));
+        started = true;
+      }
     }
+    queue_push(p, p.a.q_camera, kRowCamera, chunk, started, slot);
+    counter_add(p, kRowPaths, chunk, started);
   }
-  queue_push(p, p.a.q_shade, row_shade(p, bounce), chunk, hit_surface, slot);
+}
+
+// ---------------------------------------------------------------- extend
+// Block size in which a traversal kernel's waves take jobs from the global cursor: large enough
+// that the cursor sees few atomics, small enough that every wave comes back several times.
+RRT_DEV uint32_t grab_size(uint32_t total, uint32_t waves) {
+  const uint32_t g = (total / (4u * waves) + 63u) & ~63u;
+  return min(max(g, 64u), 1024u);
+}
+
+// Continuation rays of `parity` first (they take longest), camera rays behind them.
+template <bool COUNT>
+struct ExtendJob {
+  const RenderParams& p;
+  const uint32_t* prefix_c;
+  const uint32_t* prefix_s;
+  uint32_t n_cont, parity;
+  uint32_t slot;
+  bool cont, hit_surface;
+
+  RRT_DEV bool begin(uint32_t index, Ray* ray) {
+    cont = index < n_cont;
+    slot = cont ? queue_item(p, p.a.q_cont[parity], prefix_c, index) : queue_item(p, p.a.q_camera, prefix_s, index - n_cont);
+    const float4 o = p.a.ray_o[slot], d = p.a.ray_d[slot];
+    ray->o = mk(o);
+    ray->d = mk(d);
+    ray->tmin = 0.0f;
+    ray->tmax = kTriTMax;
+    ray->skip = -1;
+    return true;
   }
+  RRT_DEV bool advance(bool found, const Hit& tri_hit, const RayPre& r, Ray*) {
+    Hit h = tri_hit;
+    const SceneTables* sc = p.scene;
+    if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
+    hit_surface = h.prim >= 0;
+    if (hit_surface) p.a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+    return false;
+  }
+  RRT_DEV void flush(bool done, uint32_t block) {
+    queue_push(p, p.a.q_shade, kRowShade, block, done && hit_surface, slot);
+    queue_push(p, p.a.q_start[parity ^ 1u], row_start(parity ^ 1u), block, done && !hit_surface, slot | kEscaped);
+    counter_add(p, kRowContRays, block, done && cont);
+  }
+};
+
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock) k_extend(RenderParams p, uint32_t parity) {
+  RRT_DECLARE_TRACE_STACK();
+  __shared__ uint32_t prefix_c[kSegments + 1], prefix_s[kSegments + 1];
+  const uint32_t n_cont = queue_scan(p, row_cont(parity), prefix_c);
+  const uint32_t n_cam = queue_scan(p, kRowCamera, prefix_s);
+  const uint32_t total = n_cont + n_cam;
+  TraceCounters ctr = {0, 0};
+  ExtendJob<COUNT> job = {p, prefix_c, prefix_s, n_cont, parity, 0, false, false};
+  trace_stream<false, COUNT>(p.nodes, p.tris, p.scene->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0), total,
+                             grab_size(total, gridDim.x * (kTraceBlock / 64)), job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, ctr);
 }
 
 // ---------------------------------------------------------------- shade
-__global__ void __launch_bounds__(256) k_shade(RenderParams p, uint32_t bounce) {
+__global__ void __launch_bounds__(256) k_shade(RenderParams p, uint32_t parity) {
   __shared__ uint32_t prefix[kSegments + 1];
-  const uint32_t n = queue_scan(p, row_shade(p, bounce), prefix);
+  const uint32_t n = queue_scan(p, kRowShade, prefix);
+  const uint32_t next = parity ^ 1u;
   for (uint32_t chunk = blockIdx.x; chunk * 256 < n; chunk += gridDim.x) {
   const uint32_t i = chunk * 256 + threadIdx.x;
   uint32_t slot = 0;
-  bool survive = false, has_work = false, has_mis = false, has_light = false;
+  bool active = false, survive = false, has_work = false, has_mis = false, has_light = false;
   if (i < n) {
+    active = true;
     slot = queue_item(p, p.a.q_shade, prefix, i);
     const float4 o4 = p.a.ray_o[slot], d4 = p.a.ray_d[slot], h4 = p.a.hit[slot];
     const V3 org = mk(o4), dir = mk(d4);
-    V3 beta = mk(p.a.beta[slot]);
+    const uint32_t sample = __float_as_uint(o4.w), bounce = __float_as_uint(d4.w) >> 1;
+    V3 beta = mk(1.0f, 1.0f, 1.0f);
+    if (bounce > 0) beta = mk(p.a.beta[slot]);
+    else p.a.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int prim = __float_as_int(h4.x);
     const SceneTables* sc = p.scene;
     // AreaLight::emitting is zero (lights/area.rs:23-25): hitting an emitter adds nothing
     const Surface s = prim < sc->n_tris ? surface_triangle(p.tris, p.tri_shade, prim, h4.z, h4.w, dir)
                                         : surface_other(sc, prim, h4.y, org, dir);
     const DeviceMaterial m = p.materials[s.material];
-    uint32_t x, y, sample;
-    slot_pixel(p, slot, &x, &y, &sample);
+    uint32_t x, y, k;
+    slot_pixel(p, slot, &x, &y, &k);
     const uint32_t pixel = y * p.width + x;
     const Rng4 ra = rng_block(p.seed, pixel, sample, 1 + 3 * bounce);
 
@@ -344,8 +427,8 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, uint32_t bounce) 
         beta = beta / (1.0f - q);
       }
       if (survive) {
-        p.a.ray_o[slot] = f4(offset_ray_origin(s.p, s.ng, bs.wi), 0.0f);
-        p.a.ray_d[slot] = f4(bs.wi, __uint_as_float(bs.specular ? 1u : 0u));
+        p.a.ray_o[slot] = f4(offset_ray_origin(s.p, s.ng, bs.wi), o4.w);
+        p.a.ray_d[slot] = f4(bs.wi, __uint_as_float(((bounce + 1) << 1) | (bs.specular ? 1u : 0u)));
         p.a.beta[slot] = f4(beta, 0.0f);
       }
     }
@@ -353,122 +436,221 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, uint32_t bounce) 
     // without pending light the running sum is unchanged since its last clamp: nothing to do
     if (has_work) p.a.sh_c[slot] = f4(light_c, __uint_as_float(flags));
   }
-  queue_push(p, p.a.q_extend, row_extend(p, bounce + 1), chunk, survive, slot);
-  queue_push(p, p.a.q_shadow, row_shadow(p, bounce), chunk, has_work, slot);
-  counter_add(p, row_mis(p, bounce), chunk, has_mis);
-  counter_add(p, row_light(p, bounce), chunk, has_light);
+  queue_push(p, p.a.q_cont[next], row_cont(next), chunk, survive, slot);
+  queue_push(p, p.a.q_start[next], row_start(next), chunk, active && !survive, slot);
+  queue_push(p, p.a.q_shadow, kRowShadow, chunk, has_work, slot);
+  counter_add(p, kRowBounces, chunk, active);
+  counter_add(p, kRowMisRays, chunk, has_mis);
+  counter_add(p, kRowLightRays, chunk, has_light);
   }
 }
 
 // ---------------------------------------------------------------- connect
-template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams p, uint32_t bounce) {
-  RRT_DECLARE_TRACE_STACK();
-  __shared__ uint32_t prefix[kSegments + 1];
-  const uint32_t n = queue_scan(p, row_shadow(p, bounce), prefix);
-  TraceCounters ctr = {0, 0};
-  for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < n; i += gridDim.x * kTraceBlock) {
-  const uint32_t slot = queue_item(p, p.a.q_shadow, prefix, i);
-  const float4 c4 = p.a.sh_c[slot];
-  const uint32_t flags = __float_as_uint(c4.w);
-  float4 l4 = p.a.radiance[slot];
-  if (flags & kHasLightRay) {
-    const float4 o = p.a.sh_o[slot], d = p.a.sh_d[slot];
-    // two things may not occlude by identity: the surface the ray leaves (a triangle, quad or
-    // plane cannot be hit twice by a ray that starts on it) and the sampled light's own quad
-    int own = __float_as_int(p.a.hit[slot].x);
-    if (own >= p.scene->n_tris + p.scene->n_rects + p.scene->n_planes) own = -1;  // spheres keep their t > 1e-4 guard
-    if (!any_hit<COUNT>(p.nodes, p.tris, p.scene, mk(o), mk(d), o.w, own, __float_as_int(d.w), &ctr, rrt_trace_stack)) {
-      l4.x += c4.x; l4.y += c4.y; l4.z += c4.z;
+// One job = one shadow-queue entry: its light-sample ray, then its environment escape ray, then
+// the clamp; all by one lane, so the sum keeps the order of the reference's loop body.
+struct ConnectJob {
+  const RenderParams& p;
+  const uint32_t* prefix;
+  uint32_t slot, flags;
+  int stage;  // the ray in flight: 1 light sample, 2 escape ray
+  int own, light_quad;
+  float far;
+  float4 l4, c4;
+
+  RRT_DEV bool next_ray(Ray* ray) {
+    if (stage == 0 && (flags & kHasLightRay)) {
+      const float4 o = p.a.sh_o[slot], d = p.a.sh_d[slot];
+      // two things may not occlude by identity: the surface the ray leaves (a triangle, quad or
+      // plane cannot be hit twice by a ray that starts on it) and the sampled light's own quad
+      own = __float_as_int(p.a.hit[slot].x);
+      if (own >= p.scene->n_tris + p.scene->n_rects + p.scene->n_planes) own = -1;  // spheres keep their t > 1e-4 guard
+      light_quad = __float_as_int(d.w);
+      far = o.w;
+      ray->o = mk(o);
+      ray->d = mk(d);
+      ray->tmin = 0.0f;
+      ray->tmax = fminf(far, kTriTMax);
+      ray->skip = own < p.scene->n_tris ? own : -1;
+      stage = 1;
+      return true;
     }
+    if (stage <= 1 && (flags & kHasMisRay)) {
+      const float4 o = p.a.mis_o[slot], d = p.a.mis_d[slot];
+      own = light_quad = -1;
+      far = INFINITY;
+      ray->o = mk(o);
+      ray->d = mk(d);
+      ray->tmin = 0.0f;
+      ray->tmax = kTriTMax;
+      ray->skip = -1;
+      stage = 2;
+      return true;
+    }
+    if (flags & kClamp) {
+      l4.x = fminf(l4.x, p.clamp); l4.y = fminf(l4.y, p.clamp); l4.z = fminf(l4.z, p.clamp);
+    }
+    p.a.radiance[slot] = l4;
+    return false;
   }
-  if (flags & kHasMisRay) {
-    const float4 o = p.a.mis_o[slot], d = p.a.mis_d[slot], c = p.a.mis_c[slot];
-    if (!any_hit<COUNT>(p.nodes, p.tris, p.scene, mk(o), mk(d), INFINITY, -1, -1, &ctr, rrt_trace_stack)) {
+  RRT_DEV bool begin(uint32_t index, Ray* ray) {
+    slot = queue_item(p, p.a.q_shadow, prefix, index);
+    c4 = p.a.sh_c[slot];
+    flags = __float_as_uint(c4.w);
+    l4 = p.a.radiance[slot];
+    stage = 0;
+    return next_ray(ray);
+  }
+  RRT_DEV bool advance(bool found, const Hit&, const RayPre& r, Ray* ray) {
+    const SceneTables* sc = p.scene;
+    bool occluded = found;
+    if (!occluded && sc->n_rects + sc->n_planes + sc->n_spheres > 0) {
+      Hit h;
+      occluded = intersect_others<true>(sc, r, far, own, light_quad, &h);
+    }
+    if (!occluded) {
+      const float4 c = stage == 1 ? c4 : p.a.mis_c[slot];
       l4.x += c.x; l4.y += c.y; l4.z += c.z;
     }
+    return next_ray(ray);
   }
-  if (flags & kClamp) {
-    l4.x = fminf(l4.x, p.clamp); l4.y = fminf(l4.y, p.clamp); l4.z = fminf(l4.z, p.clamp);
-  }
-  p.a.radiance[slot] = l4;
-  }
+  RRT_DEV void flush(bool, uint32_t) {}
+};
+
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams p) {
+  RRT_DECLARE_TRACE_STACK();
+  __shared__ uint32_t prefix[kSegments + 1];
+  const uint32_t n = queue_scan(p, kRowShadow, prefix);
+  TraceCounters ctr = {0, 0};
+  ConnectJob job = {p, prefix, 0, 0, 0, -1, -1, 0.0f, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+  trace_stream<true, COUNT>(p.nodes, p.tris, p.scene->n_tris > 0, counter_at(p.a.counters, kRowWorkConnect, 0), n,
+                            grab_size(n, gridDim.x * (kTraceBlock / 64)), job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, ctr);
 }
 
 // ---------------------------------------------------------------- film
-// One thread per pixel of the batch: sums its n_samples radiances (they sit in
-// consecutive slots) and adds them to the film.  A pixel belongs to one thread
-// of one batch at a time, so no atomics are needed and the sum is reproducible.
+// One thread per pixel of the pass: adds the sums of its K slots to the film.  A pixel belongs to
+// one thread of one pass at a time, so no atomics are needed and the sum is reproducible.
 __global__ void __launch_bounds__(256) k_film(RenderParams p) {
   const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= p.n_tiles * 64) return;
-  uint32_t x, y, sample;
-  if (!slot_pixel(p, pix * p.n_samples, &x, &y, &sample)) return;
-  float r = 0.0f, g = 0.0f, b = 0.0f;
-  const float4* l = p.a.radiance + (size_t)pix * p.n_samples;
+  uint32_t x, y, k;
+  if (!slot_pixel(p, pix * p.n_samples, &x, &y, &k)) return;
+  float r = 0.0f, g = 0.0f, b = 0.0f, w = 0.0f;
+  const float4* acc = p.a.accum + (size_t)pix * p.n_samples;
   for (uint32_t s = 0; s < p.n_samples; ++s) {
-    const float4 v = l[s];
-    r += v.x; g += v.y; b += v.z;
+    const float4 v = acc[s];
+    r += v.x; g += v.y; b += v.z; w += v.w;
   }
   float4* out = reinterpret_cast<float4*>(p.film) + ((size_t)y * p.width + x);
   float4 f = *out;
-  f.x += r; f.y += g; f.z += b; f.w += (float)p.n_samples;
+  f.x += r; f.y += g; f.z += b; f.w += w;
   *out = f;
 }
 
-// Folds this batch's queue counters into the running statistics (one wave, lane = segment).
-__global__ void k_batch_stats(RenderParams p, unsigned long long paths) {
+// Folds the pass's running counters into the statistics (one wave, lane = segment).
+__global__ void k_pass_stats(RenderParams p) {
   const uint32_t seg = threadIdx.x;
   if (blockIdx.x != 0 || seg >= (uint32_t)kSegments) return;
-  unsigned long long extend = 0, shadow = 0, bounces = 0, mis = 0;
-  for (uint32_t b = 0; b < p.depth_limit; ++b) {
-    if (b > 0) extend += *counter_at(p.a.counters, row_extend(p, b), seg);
-    bounces += *counter_at(p.a.counters, row_shade(p, b), seg);
-    // a shadow-queue entry carries a light-sample ray, an environment escape ray, or both
-    shadow += *counter_at(p.a.counters, row_light(p, b), seg);
-    mis += *counter_at(p.a.counters, row_mis(p, b), seg);
-  }
+  unsigned long long paths = *counter_at(p.a.counters, kRowPaths, seg);
+  unsigned long long cont = *counter_at(p.a.counters, kRowContRays, seg);
+  unsigned long long bounces = *counter_at(p.a.counters, kRowBounces, seg);
+  // a shadow-queue entry carries a light-sample ray, an environment escape ray, or both
+  unsigned long long shadow = (unsigned long long)*counter_at(p.a.counters, kRowLightRays, seg) +
+                              *counter_at(p.a.counters, kRowMisRays, seg);
   for (int d = kSegments / 2; d > 0; d >>= 1) {
-    extend += __shfl_down(extend, d);
-    shadow += __shfl_down(shadow, d);
+    paths += __shfl_down(paths, d);
+    cont += __shfl_down(cont, d);
     bounces += __shfl_down(bounces, d);
-    mis += __shfl_down(mis, d);
+    shadow += __shfl_down(shadow, d);
   }
   if (seg == 0) {
     p.stats->paths += paths;
-    p.stats->rays_extend += paths + extend;
+    p.stats->rays_extend += paths + cont;
     p.stats->path_bounces += bounces;
-    p.stats->rays_shadow += shadow + mis;
+    p.stats->rays_shadow += shadow;
   }
 }
 
 // ---------------------------------------------------------------- parity hooks
+struct IntersectJob {
+  const TriIsect* tris;
+  const SceneTables* sc;
+  const float* org_dir;
+  int32_t* prim_id;
+  float* t_out;
+  uint32_t index;
+
+  RRT_DEV bool begin(uint32_t i, Ray* ray) {
+    index = i;
+    const float* r = org_dir + (size_t)i * 6;
+    ray->o = mk(r[0], r[1], r[2]);
+    ray->d = mk(r[3], r[4], r[5]);
+    ray->tmin = 0.0f;
+    ray->tmax = kTriTMax;
+    ray->skip = -1;
+    return true;
+  }
+  RRT_DEV bool advance(bool, const Hit& tri_hit, const RayPre& r, Ray*) {
+    Hit h = tri_hit;
+    if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
+    int id = h.prim;
+    if (id >= 0 && id < sc->n_tris) id = __float_as_int(tris[id].v0.w);  // leaf order -> scene order
+    prim_id[index] = id;
+    t_out[index] = h.prim >= 0 ? h.t : 0.0f;
+    return false;
+  }
+  RRT_DEV void flush(bool, uint32_t) {}
+};
+
 __global__ void __launch_bounds__(kTraceBlock) k_intersect(const BvhNode* nodes, const TriIsect* tris,
                                                            const SceneTables* sc, const float* __restrict__ org_dir,
-                                                           uint32_t n, int32_t* prim_id, float* t_out) {
+                                                           uint32_t n, int32_t* prim_id, float* t_out, uint32_t* work_cursor) {
   RRT_DECLARE_TRACE_STACK();
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* r = org_dir + (size_t)i * 6;
   TraceCounters ctr = {0, 0};
-  const Hit h = closest_hit<false>(nodes, tris, sc, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), &ctr, rrt_trace_stack);
-  int id = h.prim;
-  if (id >= 0 && id < sc->n_tris) id = __float_as_int(tris[id].v0.w);  // leaf order -> scene order
-  prim_id[i] = id;
-  t_out[i] = h.prim >= 0 ? h.t : 0.0f;
+  IntersectJob job = {tris, sc, org_dir, prim_id, t_out, 0};
+  trace_stream<false, false>(nodes, tris, sc->n_tris > 0, work_cursor, n, grab_size(n, gridDim.x * (kTraceBlock / 64)), job,
+                             &ctr, rrt_trace_stack);
 }
+
+struct OccludedJob {
+  const SceneTables* sc;
+  const float* odt;
+  uint8_t* out;
+  uint32_t index;
+  float far;
+
+  RRT_DEV bool begin(uint32_t i, Ray* ray) {
+    index = i;
+    const float* r = odt + (size_t)i * 7;
+    far = r[6];
+    ray->o = mk(r[0], r[1], r[2]);
+    ray->d = mk(r[3], r[4], r[5]);
+    ray->tmin = 0.0f;
+    ray->tmax = fminf(far, kTriTMax);
+    ray->skip = -1;
+    return true;
+  }
+  RRT_DEV bool advance(bool found, const Hit&, const RayPre& r, Ray*) {
+    bool occluded = found;
+    if (!occluded && sc->n_rects + sc->n_planes + sc->n_spheres > 0) {
+      Hit h;
+      occluded = intersect_others<true>(sc, r, far, -1, -1, &h);
+    }
+    out[index] = occluded ? 1 : 0;
+    return false;
+  }
+  RRT_DEV void flush(bool, uint32_t) {}
+};
 
 __global__ void __launch_bounds__(kTraceBlock) k_occluded(const BvhNode* nodes, const TriIsect* tris,
                                                           const SceneTables* sc, const float* __restrict__ odt,
-                                                          uint32_t n, uint8_t* out) {
+                                                          uint32_t n, uint8_t* out, uint32_t* work_cursor) {
   RRT_DECLARE_TRACE_STACK();
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* r = odt + (size_t)i * 7;
   TraceCounters ctr = {0, 0};
-  out[i] = any_hit<false>(nodes, tris, sc, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), r[6], -1, -1, &ctr,
-                          rrt_trace_stack) ? 1 : 0;
+  OccludedJob job = {sc, odt, out, 0, 0.0f};
+  trace_stream<true, false>(nodes, tris, sc->n_tris > 0, work_cursor, n, grab_size(n, gridDim.x * (kTraceBlock / 64)), job, &ctr,
+                            rrt_trace_stack);
 }
 
 }  // namespace rrt

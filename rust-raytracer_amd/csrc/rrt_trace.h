@@ -20,26 +20,27 @@ constexpr float kTriTMax = 1000.0f;  // objects/triangle.rs:164-171
 // conflicts); deeper entries -- rare -- spill to a per-lane array in scratch memory.
 constexpr int kTraceBlock = 256;   // threads per block of every kernel that traverses
 #ifndef RRT_LDS_STACK_DEPTH
-#define RRT_LDS_STACK_DEPTH 0  // measured: 0 (all in scratch) beats 12, 16 and 24 -- LDS costs a wave of occupancy
+#define RRT_LDS_STACK_DEPTH 12  // measured: 12 beats 0 (all in scratch) by 15% and 24 by 3%
 #endif
 constexpr int kLdsDepth = RRT_LDS_STACK_DEPTH;
 constexpr int kSpillDepth = 96 - kLdsDepth;  // 96 entries in all: deeper than any tree the builder makes (SAH depth <= 40 + median levels)
 #define RRT_DECLARE_TRACE_STACK() __shared__ int rrt_trace_stack[(rrt::kLdsDepth > 0 ? rrt::kLdsDepth : 1) * rrt::kTraceBlock]
 
-struct TraceStack {
-  int* lds;  // this thread's column: entry e at lds[e * kTraceBlock]
-  int spill[kSpillDepth];
-  int sp;
-  RRT_DEV void push(int v) {
-    if (sp < kLdsDepth) lds[sp * kTraceBlock] = v;
-    else if (sp < kLdsDepth + kSpillDepth) spill[sp - kLdsDepth] = v;
-    ++sp;
-  }
-  RRT_DEV int pop() {
-    --sp;
-    return sp < kLdsDepth ? lds[sp * kTraceBlock] : spill[min(sp - kLdsDepth, kSpillDepth - 1)];
-  }
-};
+// The stack pointer is a plain local of the traversal loop, and the spill array a local of its
+// own: as members of one struct next to a dynamically indexed array they would all be placed in
+// scratch memory, and every push and pop would reload the stack pointer from there.
+#define RRT_STACK_PUSH(v)                                                        \
+  do {                                                                           \
+    if (kLdsDepth > 0 && sp < kLdsDepth) lds[sp * kTraceBlock] = (v);            \
+    else spill[min(sp - kLdsDepth, kSpillDepth - 1)] = (v);                      \
+    ++sp;                                                                        \
+  } while (0)
+#define RRT_STACK_POP(dst)                                                       \
+  do {                                                                           \
+    --sp;                                                                        \
+    if (kLdsDepth > 0 && sp < kLdsDepth) (dst) = lds[sp * kTraceBlock];          \
+    else (dst) = spill[min(sp - kLdsDepth, kSpillDepth - 1)];                    \
+  } while (0)
 
 struct RayPre {
   V3 o, d, inv, ood;  // ood = o * inv
@@ -97,62 +98,181 @@ struct TraceCounters {
   uint32_t nodes, tris;
 };
 
-// Closest (ANY = false) or any (ANY = true) triangle hit with t in (tmin, tmax).
-// `skip` is a leaf-order triangle that is never reported (the surface a shadow
-// ray leaves), or -1.  Returns true when something was hit.
-template <bool ANY, bool COUNT>
-RRT_DEV bool traverse_tris(const BvhNode* __restrict__ nodes, const TriIsect* __restrict__ tris, const RayPre& r,
-                           float tmin, float tmax, int skip, Hit* hit, TraceCounters* ctr, int* lds_stack) {
-  TraceStack stack;
-  stack.lds = lds_stack + threadIdx.x;
-  stack.sp = 0;
-  int cur = 0;
+struct Ray {
+  V3 o, d;
+  float tmin, tmax;
+  int skip;  // a leaf-order triangle that is never reported (the surface a shadow ray leaves), or -1
+};
+
+// ---------------------------------------------------------------- the traversal engine
+// A wave streams through a queue of jobs instead of taking 64 of them and waiting for the slowest:
+// rays differ in length by an order of magnitude, and with one ray per lane per launch only 1 lane
+// in 5 (closest hit) or 1 in 10 (visibility) was doing work at any time.  Here every lane is a small
+// state machine; a lane whose ray is finished hands in its result and takes the next job as soon as
+// kRefillQuorum lanes are free, so the wave stays mostly full until the queue is empty.
+//
+// Job indices come from a global cursor in blocks of `grab` (one atomic per block per wave), which
+// also balances the load between waves.  A job is a type with
+//   bool begin(uint32_t index, Ray* ray)       first ray of job `index`; false: the job needs no ray
+//   bool advance(bool found, const Hit& hit, const RayPre& r, Ray* ray)
+//                                              a ray is done (triangles only: the job looks at the
+//                                              analytic shapes itself); true: `ray` is its next one
+//   void flush(bool done, uint32_t block)      wave-collective; `done` lanes completed a job taken
+//                                              from index block `block` since the last flush
+// Closest hit (ANY = false) or any hit (ANY = true) with t in (tmin, tmax).
+//
+// Inside the loop the lanes at inner nodes step together until kLeafQuorum of the travelling lanes
+// have reached a leaf, then those test their triangles (the while-while scheme, without making
+// every lane wait for the last straggler to arrive at a leaf).
+#ifndef RRT_REFILL_QUORUM
+#define RRT_REFILL_QUORUM 16
+#endif
+#ifndef RRT_LEAF_FRACTION
+#define RRT_LEAF_FRACTION 4  // leaf phase when 1/4 of the travelling lanes are at a leaf
+#endif
+
+template <bool ANY, bool COUNT, class Job>
+RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __restrict__ tris, bool has_tris,
+                          uint32_t* work_cursor, uint32_t total, uint32_t grab, Job& job, TraceCounters* ctr,
+                          int* lds_stack) {
+  enum { kIdle = 0, kTravelling = 1, kArrived = 2, kJobDone = 3 };
+  int* lds = lds_stack + threadIdx.x;  // this thread's column: entry e at lds[e * kTraceBlock]
+  int spill[kSpillDepth];
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  uint32_t cursor = 0, end = 0, block = 0;  // wave-uniform: the index block being handed out
+  bool exhausted = false;                   // wave-uniform: the global cursor has run past `total`
+  int state = kIdle;
+  uint32_t my_block = 0;
+  RayPre r;
+  r.o = r.d = r.inv = r.ood = mk(0.0f, 0.0f, 0.0f);
+  float tmin = 0.0f, tmax = 0.0f;
+  int skip = -1, cur = 0, sp = 0;
+  Hit hit;
+  hit.prim = -1;
+  hit.t = INFINITY;
+  hit.u = hit.v = 0.0f;
   bool found = false;
-  const int kDone = 0x7fffffff;
-  while (cur != kDone) {
-    while (cur >= 0 && cur != kDone) {
-      const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-      const float4 n0 = np[0], n1 = np[1], n2 = np[2];
-      const int4 n3 = reinterpret_cast<const int4*>(np)[3];
-      if (COUNT) ctr->nodes++;
-      const float tl = slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tmin, tmax);
-      const float tr = slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tmin, tmax);
-      const bool hl = tl < INFINITY, hr = tr < INFINITY;
-      if (hl && hr) {
-        const bool left_first = tl <= tr;
-        const int nearc = left_first ? n3.x : n3.y;
-        const int farc = left_first ? n3.y : n3.x;
-        stack.push(farc);
-        cur = nearc;
-      } else if (hl) {
-        cur = n3.x;
-      } else if (hr) {
-        cur = n3.y;
-      } else {
-        cur = stack.sp > 0 ? stack.pop() : kDone;
-      }
+
+#define RRT_START_RAY(ray)                                   \
+  do {                                                       \
+    r = prepare_ray((ray).o, (ray).d);                       \
+    tmin = (ray).tmin;                                       \
+    tmax = (ray).tmax;                                       \
+    skip = (ray).skip;                                       \
+    hit.prim = -1;                                           \
+    hit.t = INFINITY;                                        \
+    found = false;                                           \
+    sp = 0;                                                  \
+    cur = 0;                                                 \
+    state = has_tris ? kTravelling : kArrived;               \
+  } while (0)
+#define RRT_POP_OR_ARRIVE()                                  \
+  do {                                                       \
+    if (sp > 0) RRT_STACK_POP(cur);                          \
+    else state = kArrived;                                   \
+  } while (0)
+
+  for (;;) {
+    if (state == kArrived) {
+      Ray ray;
+      if (job.advance(found, hit, r, &ray)) RRT_START_RAY(ray);
+      else state = kJobDone;
     }
-    if (cur == kDone) break;
-    // leaf: ~cur = first << 2 | (count - 1)
-    const int code = ~cur;
-    const int first = code >> 2, cnt = (code & 3) + 1;
-    for (int i = 0; i < cnt; ++i) {
-      const int ti = first + i;
-      if (COUNT) ctr->tris++;
-      float t, u, v;
-      if (ti != skip && intersect_tri(tris, ti, r, tmin, tmax, &t, &u, &v)) {
-        if (ANY) return true;
-        tmax = t;
-        hit->prim = ti;
-        hit->t = t;
-        hit->u = u;
-        hit->v = v;
-        found = true;
-      }
+    // hand in finished jobs, one index block at a time
+    unsigned long long done_mask = __ballot(state == kJobDone);
+    while (done_mask) {
+      const uint32_t b = __shfl(my_block, __ffsll((long long)done_mask) - 1);
+      const bool mine = state == kJobDone && my_block == b;
+      job.flush(mine, b);
+      if (mine) state = kIdle;
+      done_mask &= ~__ballot(mine);
     }
-    cur = stack.sp > 0 ? stack.pop() : kDone;
+    // refill idle lanes (a second pass when the first one ran into the end of an index block)
+    for (int pass = 0; pass < 2; ++pass) {
+      const unsigned long long idle_mask = __ballot(state == kIdle);
+      if (idle_mask == 0 || exhausted) break;
+      if (cursor >= end) {
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(work_cursor, grab);
+        g = __shfl(g, 0);
+        if (g >= total) {
+          exhausted = true;
+          break;
+        }
+        cursor = g;
+        end = min(g + grab, total);
+        block = g / grab;
+      }
+      const uint32_t index = cursor + (uint32_t)__popcll(idle_mask & lanes_below);
+      if (state == kIdle && index < end) {
+        my_block = block;
+        Ray ray;
+        if (job.begin(index, &ray)) RRT_START_RAY(ray);
+        else state = kJobDone;
+      }
+      cursor = min(end, cursor + (uint32_t)__popcll(idle_mask));
+    }
+    if (__ballot(state == kTravelling) == 0) {
+      if (__ballot(state != kIdle) == 0 && exhausted) break;
+      continue;
+    }
+
+    // ---- traversal until enough lanes have arrived to make a refill worth its cost
+    for (;;) {
+      for (;;) {
+        if (state == kTravelling && cur >= 0) {
+          const float4* np = reinterpret_cast<const float4*>(nodes + cur);
+          const float4 n0 = np[0], n1 = np[1], n2 = np[2];
+          const int4 n3 = reinterpret_cast<const int4*>(np)[3];
+          if (COUNT) ctr->nodes++;
+          const float tl = slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tmin, tmax);
+          const float tr = slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tmin, tmax);
+          const bool hl = tl < INFINITY, hr = tr < INFINITY;
+          if (hl && hr) {
+            const bool left_first = tl <= tr;
+            const int farc = left_first ? n3.y : n3.x;
+            RRT_STACK_PUSH(farc);
+            cur = left_first ? n3.x : n3.y;
+          } else if (hl) {
+            cur = n3.x;
+          } else if (hr) {
+            cur = n3.y;
+          } else {
+            RRT_POP_OR_ARRIVE();
+          }
+        }
+        const unsigned long long inner = __ballot(state == kTravelling && cur >= 0);
+        const unsigned long long at_leaf = __ballot(state == kTravelling && cur < 0);
+        if (inner == 0 || RRT_LEAF_FRACTION * __popcll(at_leaf) >= __popcll(inner | at_leaf)) break;
+      }
+      if (state == kTravelling && cur < 0) {
+        // leaf: ~cur = first << 2 | (count - 1)
+        const int code = ~cur;
+        const int first = code >> 2, cnt = (code & 3) + 1;
+        for (int i = 0; i < cnt; ++i) {
+          const int ti = first + i;
+          if (COUNT) ctr->tris++;
+          float t, u, v;
+          if (ti != skip && intersect_tri(tris, ti, r, tmin, tmax, &t, &u, &v)) {
+            found = true;
+            if (ANY) break;
+            tmax = t;
+            hit.prim = ti;
+            hit.t = t;
+            hit.u = u;
+            hit.v = v;
+          }
+        }
+        if (ANY && found) state = kArrived;
+        else RRT_POP_OR_ARRIVE();
+      }
+      const unsigned long long arrived = __ballot(state == kArrived);
+      if (__ballot(state == kTravelling) == 0 || __popcll(arrived) >= RRT_REFILL_QUORUM) break;
+    }
   }
-  return found;
+#undef RRT_START_RAY
+#undef RRT_POP_OR_ARRIVE
 }
 
 // The reference finds a quad only if the bvh crate's box test lets its leaf
@@ -244,37 +364,6 @@ RRT_DEV bool intersect_others(const SceneTables* __restrict__ sc, const RayPre& 
     }
   }
   return found;
-}
-
-// check_intersect_scene
-template <bool COUNT>
-RRT_DEV Hit closest_hit(const BvhNode* __restrict__ nodes, const TriIsect* __restrict__ tris,
-                        const SceneTables* __restrict__ sc, V3 o, V3 d, TraceCounters* ctr, int* lds_stack) {
-  Hit hit;
-  hit.prim = -1;
-  hit.t = INFINITY;
-  hit.u = hit.v = 0.0f;
-  const RayPre r = prepare_ray(o, d);
-  if (sc->n_tris > 0) traverse_tris<false, COUNT>(nodes, tris, r, 0.0f, kTriTMax, -1, &hit, ctr, lds_stack);
-  if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, hit.t, -1, -1, &hit);
-  return hit;
-}
-
-// check_intersect_scene_simple: anything closer than tmax?
-template <bool COUNT>
-RRT_DEV bool any_hit(const BvhNode* __restrict__ nodes, const TriIsect* __restrict__ tris,
-                     const SceneTables* __restrict__ sc, V3 o, V3 d, float tmax, int skip_a, int skip_b,
-                     TraceCounters* ctr, int* lds_stack) {
-  const RayPre r = prepare_ray(o, d);
-  Hit hit;
-  // only skip_a can name a triangle (the surface a ray leaves); skip_b names a light's quad
-  if (sc->n_tris > 0 &&
-      traverse_tris<true, COUNT>(nodes, tris, r, 0.0f, fminf(tmax, kTriTMax), skip_a < sc->n_tris ? skip_a : -1, &hit,
-                                 ctr, lds_stack))
-    return true;
-  if (sc->n_rects + sc->n_planes + sc->n_spheres > 0 && intersect_others<true>(sc, r, tmax, skip_a, skip_b, &hit))
-    return true;
-  return false;
 }
 
 }  // namespace rrt
