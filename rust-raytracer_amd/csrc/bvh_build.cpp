@@ -4,14 +4,17 @@
 // src/scene.rs:196) and only ever uses it as a conservative candidate filter
 // (src/renderer.rs:226-246): the closest hit is the minimum over exact tests,
 // so any correct hierarchy over the same triangles gives the same answer.
-// This one is built for the GPU: binned SAH (16 bins, all three axes), leaves
-// of up to 4 triangles stored contiguously, two child boxes per 64-byte node,
-// nodes laid out in depth-first order, subtrees built on separate threads.
+// This one is built for the GPU: a binary tree by binned SAH (16 bins, all three
+// axes; subtrees built on separate threads) with leaves of up to 4 triangles
+// stored contiguously, then collapsed into 4-wide nodes -- each node adopts the
+// grandchildren of its largest children until it has four -- laid out in
+// depth-first order.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -38,6 +41,15 @@ struct Box {
   }
 };
 
+// Node of the binary tree the SAH pass builds.  child >= 0: inner node; child < 0: leaf
+// reference (see BvhNode); lcount / rcount: triangles in a leaf child, 0 for an inner child.
+struct Node2 {
+  float lmin[3], lmax[3];
+  float rmin[3], rmax[3];
+  int32_t left, right;
+  int32_t lcount, rcount;
+};
+
 constexpr int kBins = 16;
 constexpr uint32_t kMaxLeaf = 4;
 constexpr uint32_t kSahDepthLimit = 40;     // below this depth splits fall back to the object median
@@ -48,7 +60,7 @@ struct Builder {
   uint32_t n;
   std::vector<float> tmin, tmax, cent;  // [n][3]
   uint32_t* idx;
-  BvhNode* nodes;
+  Node2* nodes;
   std::atomic<uint32_t> node_count{0};
   std::atomic<int> free_threads{0};
   std::atomic<uint32_t> max_depth{0};
@@ -160,7 +172,7 @@ struct Builder {
     }
 
     const uint32_t me = node_count.fetch_add(1, std::memory_order_relaxed);
-    BvhNode node;
+    Node2 node;
     std::memset(&node, 0, sizeof(node));
     Box lb, rb;
     int32_t lc, lcount, rc, rcount;
@@ -190,50 +202,88 @@ struct Builder {
   }
 };
 
-// Rewrites the nodes in depth-first pre-order so that a node's left child
-// follows it in memory.
-void relayout(const BvhNode* in, BvhNode* out, uint32_t n_nodes) {
-  if (n_nodes == 0) return;
-  std::vector<std::pair<uint32_t, uint32_t>> stack;  // (old index, slot in `out` of the reference to patch: parent*2+side)
-  uint32_t next = 0;
-  stack.emplace_back(0u, UINT32_MAX);
-  while (!stack.empty()) {
-    const auto [old_i, patch] = stack.back();
-    stack.pop_back();
-    const uint32_t me = next++;
-    out[me] = in[old_i];
-    if (patch != UINT32_MAX) {
-      if (patch & 1) out[patch >> 1].right = (int32_t)me;
-      else out[patch >> 1].left = (int32_t)me;
+// Collapses the binary tree into 4-wide nodes, emitted in depth-first pre-order.
+struct Collapser {
+  const Node2* in;
+  std::vector<BvhNode> out;
+  uint32_t max_depth = 0;
+
+  struct Child {
+    Box box;
+    int32_t ref;    // binary-tree reference: inner index or leaf code
+    bool inner;
+  };
+
+  static void children_of(const Node2& n, Child* l, Child* r) {
+    for (int k = 0; k < 3; ++k) {
+      l->box.mn[k] = n.lmin[k]; l->box.mx[k] = n.lmax[k];
+      r->box.mn[k] = n.rmin[k]; r->box.mx[k] = n.rmax[k];
     }
-    // push right first so that the left subtree is emitted first
-    if (in[old_i].rcount == 0 && in[old_i].right >= 0) stack.emplace_back((uint32_t)in[old_i].right, me * 2 + 1);
-    if (in[old_i].lcount == 0 && in[old_i].left >= 0) stack.emplace_back((uint32_t)in[old_i].left, me * 2);
+    l->ref = n.left; l->inner = n.lcount == 0 && n.left >= 0;
+    r->ref = n.right; r->inner = n.rcount == 0 && n.right >= 0;
   }
-}
+
+  // Emits the 4-wide node for binary node `old_i`; returns its index in `out`.
+  uint32_t emit(uint32_t old_i, uint32_t depth) {
+    max_depth = std::max(max_depth, depth);
+    Child c[4];
+    int n = 2;
+    children_of(in[old_i], &c[0], &c[1]);
+    // an absent right child (single-leaf scene) has an inverted box: drop it
+    if (!(c[1].box.mx[0] >= c[1].box.mn[0])) n = 1;
+    while (n < 4) {
+      int best = -1;
+      float best_area = -1.0f;
+      for (int i = 0; i < n; ++i)
+        if (c[i].inner && c[i].box.half_area() > best_area) { best = i; best_area = c[i].box.half_area(); }
+      if (best < 0) break;
+      Child l, r;
+      children_of(in[c[best].ref], &l, &r);
+      c[best] = l;
+      c[n++] = r;
+    }
+    const uint32_t me = (uint32_t)out.size();
+    out.emplace_back();
+    BvhNode node;
+    std::memset(&node, 0, sizeof(node));
+    for (int i = 0; i < 4; ++i) {
+      if (i < n) {
+        node.lo_x[i] = c[i].box.mn[0]; node.lo_y[i] = c[i].box.mn[1]; node.lo_z[i] = c[i].box.mn[2];
+        node.hi_x[i] = c[i].box.mx[0]; node.hi_y[i] = c[i].box.mx[1]; node.hi_z[i] = c[i].box.mx[2];
+        node.child[i] = c[i].ref;  // inner references are patched below
+      } else {
+        node.lo_x[i] = node.lo_y[i] = node.lo_z[i] = INFINITY;
+        node.hi_x[i] = node.hi_y[i] = node.hi_z[i] = -INFINITY;
+        node.child[i] = ~0;
+      }
+    }
+    for (int i = 0; i < n; ++i)
+      if (c[i].inner) node.child[i] = (int32_t)emit((uint32_t)c[i].ref, depth + 1);
+    out[me] = node;
+    return me;
+  }
+};
 
 }  // namespace
 
 bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuildResult* out) {
   *out = BvhBuildResult();
   const uint32_t cap = n_tris > 1 ? n_tris : 1;
-  BvhNode* scratch = (BvhNode*)std::malloc(sizeof(BvhNode) * (size_t)cap);
+  Node2* scratch = (Node2*)std::malloc(sizeof(Node2) * (size_t)cap);
   uint32_t* order = (uint32_t*)std::malloc(sizeof(uint32_t) * (size_t)cap);
   if (!scratch || !order) { std::free(scratch); std::free(order); return false; }
 
   auto empty_child = [](float* mn, float* mx) {
     for (int k = 0; k < 3; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
   };
-  uint32_t n_nodes = 0;
-  uint32_t depth = 0;
   if (n_tris == 0) {
-    BvhNode root;
+    Node2 root;
     std::memset(&root, 0, sizeof(root));
     empty_child(root.lmin, root.lmax);
     empty_child(root.rmin, root.rmax);
     root.left = root.right = ~0;
+    root.lcount = root.rcount = 1;  // not inner
     scratch[0] = root;
-    n_nodes = 1;
   } else {
     Builder b;
     b.pos = tri_pos;
@@ -248,30 +298,40 @@ bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuild
     int32_t child, count;
     Box box;
     b.build(0, n_tris, 0, &child, &count, &box);
-    n_nodes = b.node_count.load();
-    depth = b.max_depth.load();
     if (count > 0) {  // the whole scene is one leaf: wrap it in a root node
-      BvhNode root;
+      Node2 root;
       std::memset(&root, 0, sizeof(root));
       for (int k = 0; k < 3; ++k) { root.lmin[k] = box.mn[k]; root.lmax[k] = box.mx[k]; }
       empty_child(root.rmin, root.rmax);
       root.left = child;
       root.lcount = count;
       root.right = ~0;
-      root.rcount = 0;
+      root.rcount = 1;
       scratch[0] = root;
-      n_nodes = 1;
     }
   }
-  BvhNode* nodes = (BvhNode*)std::malloc(sizeof(BvhNode) * (size_t)n_nodes);
-  if (!nodes) { std::free(scratch); std::free(order); return false; }
-  // the root of a multi-node tree is whichever node the top-level call allocated: index 0
-  relayout(scratch, nodes, n_nodes);
+  // the root of a multi-node binary tree is whichever node the top-level call allocated: index 0
+  Collapser col;
+  col.in = scratch;
+  try {
+    col.emit(0, 1);
+  } catch (const std::bad_alloc&) {
+    std::free(scratch);
+    std::free(order);
+    return false;
+  }
   std::free(scratch);
+  const uint32_t n_nodes = (uint32_t)col.out.size();
+  BvhNode* nodes = nullptr;
+  if (posix_memalign((void**)&nodes, alignof(BvhNode), sizeof(BvhNode) * (size_t)n_nodes) != 0) {
+    std::free(order);
+    return false;
+  }
+  std::memcpy(nodes, col.out.data(), sizeof(BvhNode) * (size_t)n_nodes);
   out->nodes = nodes;
   out->n_nodes = n_nodes;
   out->order = order;
-  out->max_depth = depth;
+  out->max_depth = col.max_depth;
   return true;
 }
 

@@ -165,9 +165,15 @@ int ensure_state(rrt_ctx* ctx, uint32_t n_slots, uint32_t depth, bool need_mis) 
   // (extend hands in results per index block of at most 1024 jobs, shade per chunk of 256.)
   a.seg_cap = 2 * ((n_slots + kSegments - 1) / kSegments) + n_slots / 2048 + 4096;
   const size_t queue_words = (size_t)a.seg_cap * kSegments;
-  uint32_t** queues[] = {&a.q_start[0], &a.q_start[1], &a.q_cont[0], &a.q_cont[1], &a.q_camera, &a.q_shade, &a.q_shadow};
+  uint32_t** queues[] = {&a.q_start[0], &a.q_start[1], &a.q_shade, &a.q_shadow};
   for (uint32_t** q : queues)
     if ((rc = state_alloc(ctx, q, queue_words)) != RRT_OK) return rc;
+  // ray queues have one producer each (shade, start), handing in per chunk of 256
+  a.ray_seg_cap = (n_slots + kSegments - 1) / kSegments + 1024;
+  float4** ray_queues[] = {&a.rays_cont[0], &a.rays_cont[1], &a.rays_camera};
+  for (float4** q : ray_queues)
+    if ((rc = state_alloc(ctx, q, (size_t)a.ray_seg_cap * kSegments * 2)) != RRT_OK) return rc;
+  if ((rc = state_alloc(ctx, &a.sample, n_slots)) != RRT_OK) return rc;
   if ((rc = state_alloc(ctx, &a.counters, (size_t)kCounterRows * kSegments * kCounterStride)) != RRT_OK) return rc;
   if (!ctx->h_pending)
     HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_pending, sizeof(uint32_t) * 2 * kSegments * kCounterStride, hipHostMallocDefault));
@@ -545,6 +551,12 @@ int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   std::vector<DeviceMaterial> mats(sd->n_materials);
   for (uint32_t i = 0; i < sd->n_materials; ++i) mats[i] = digest_material(sd->materials[i]);
 
+  // every 4-wide node on a ray's way down leaves at most 3 entries on the traversal stack
+  if (3ull * bvh.max_depth + 1 > (uint64_t)kStackDepth) {
+    free_bvh(&bvh);
+    return fail(ctx, RRT_E_UNSUPPORTED, "hierarchy too deep for the traversal stack");
+  }
+
   // ---- upload
   ctx->n_nodes = bvh.n_nodes;
   rc = dev_alloc(ctx, &ctx->d_nodes, bvh.n_nodes);
@@ -808,6 +820,18 @@ int rrt_get_stats(rrt_ctx* ctx, rrt_stats* out) {
   out->launches_extend = ctx->launches_extend;
   out->bvh_nodes = ctx->n_nodes;
   out->bvh_bytes = ctx->bvh_bytes;
+#ifdef RRT_PHASE_CLOCKS
+  {
+    unsigned long long dbg[32];
+    if (hipMemcpyFromSymbol(dbg, HIP_SYMBOL(rrt_phase_dbg), sizeof(dbg)) == hipSuccess) {
+      for (int k = 0; k < 32; k += 16)
+        std::fprintf(stderr, "phase clocks (%s): refill %llu (advance %llu begin %llu flush %llu) node %llu leaf %llu | node iters %llu leaf iters %llu | lanes stepping %llu at leaf %llu | refills %llu total %llu\n",
+                     k ? "any hit" : "closest hit", dbg[k + 0], dbg[k + 10], dbg[k + 11], dbg[k + 12], dbg[k + 1], dbg[k + 2], dbg[k + 3], dbg[k + 4], dbg[k + 5], dbg[k + 6], dbg[k + 7], dbg[k + 8]);
+      std::memset(dbg, 0, sizeof(dbg));
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(rrt_phase_dbg), dbg, sizeof(dbg));
+    }
+  }
+#endif
   return RRT_OK;
 }
 

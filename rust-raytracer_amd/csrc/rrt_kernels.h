@@ -23,16 +23,26 @@
 // The result does not depend on the schedule: a path is a function of (seed, pixel, sample), a
 // slot adds its finished paths in sample order, and film adds a pixel's slots in slot order.
 //
-// Queues hold slot numbers and are rebuilt by every kernel with a wave ballot + prefix count + one
+// Queues hold slot numbers and are rebuilt by every kernel with a wave ballot + lane count + one
 // atomic per wave.  They are split into kSegments segments with a counter each: one counter for a
 // whole launch would take one returning atomic per wave on ONE address -- about 11 ns each, 2
 // million of them for a 33 M-slot launch -- and that, not the ray tracing, would set the kernel
 // time.  Chunk c of a launch appends to segment c % kSegments.
 #pragma once
+#include <stddef.h>
+
 #include "rrt_device.h"
 #include "rrt_math.h"
 #include "rrt_shade.h"
 #include "rrt_trace.h"
+
+// Launch bounds of the kernels that traverse: the second figure (waves per SIMD the register
+// allocator has to make room for) trades registers per ray against rays in flight.
+#ifdef RRT_TRACE_WAVES
+#define RRT_TRACE_BOUNDS __launch_bounds__(rrt::kTraceBlock, RRT_TRACE_WAVES)
+#else
+#define RRT_TRACE_BOUNDS __launch_bounds__(rrt::kTraceBlock)
+#endif
 
 namespace rrt {
 
@@ -65,8 +75,9 @@ RRT_DEV uint32_t row_start(uint32_t parity) { return parity ? kRowStart1 : kRowS
 RRT_DEV uint32_t row_cont(uint32_t parity) { return parity ? kRowCont1 : kRowCont0; }
 
 struct PathArrays {
-  float4* ray_o;      // xyz origin, w = sample index of the slot's current path (uint bits)
-  float4* ray_d;      // xyz direction, w = bounce << 1 | previous bounce sampled a specular lobe
+  float4* ray_o;      // xyz origin of the ray that produced `hit` (written by extend when the ray hits)
+  float4* ray_d;      // xyz direction of the slot's last ray, w = bounce << 1 | previous bounce sampled a specular lobe
+  uint32_t* sample;   // sample index of the slot's current path
   float4* beta;       // path throughput (`contribution` in the reference); 1 at bounce 0 and not stored
   float4* radiance;   // L of the current path; written by shade at bounce 0
   float4* accum;      // sum of the slot's finished paths, w = their number
@@ -78,8 +89,12 @@ struct PathArrays {
   float4* mis_d;
   float4* mis_c;
   uint32_t* q_start[2];  // slots whose path has ended (or not begun), with entry flags
-  uint32_t* q_cont[2];   // slots with a continuation ray
-  uint32_t* q_camera;    // slots with a new camera ray
+  // Ray queues carry the rays themselves, two float4 per entry: (origin, slot bits), (direction,
+  // state bits as in ray_d).  A traversing lane that takes a new job then needs one memory round
+  // trip, over consecutive addresses, instead of entry -> slot -> ray.
+  float4* rays_cont[2];  // continuation rays
+  float4* rays_camera;   // new camera rays
+  uint32_t ray_seg_cap;  // capacity of one segment of a ray queue
   uint32_t* q_shade;     // slots whose ray hit a surface this iteration
   uint32_t* q_shadow;    // slots with visibility work this iteration
   uint32_t* counters;    // kCounterRows rows of kSegments counters
@@ -125,21 +140,34 @@ RRT_DEV bool slot_pixel(const RenderParams& p, uint32_t slot, uint32_t* x, uint3
   return lx < p.win_w && ly < p.win_h;
 }
 
-// Appends `entry` of every lane with `keep` to a queue: one atomic per wave, on the counter of
+// Reserves a queue position for every lane with `keep`: one atomic per wave, on the counter of
 // segment chunk % kSegments, where `chunk` numbers the block of work items the lanes are working
-// on (the same for all lanes that push together).  A segment can overflow only if the chunks that
-// map to it produce more than seg_cap entries; callers size seg_cap from their chunk sizes.
-RRT_DEV void queue_push(const RenderParams& p, uint32_t* __restrict__ queue, uint32_t row, uint32_t chunk, bool keep,
-                        uint32_t entry) {
+// on (the same for all lanes that push together).  Returns the position (segment * cap + index in
+// the segment); lanes without `keep` get garbage.  A segment can overflow only if the chunks that
+// map to it produce more than `cap` entries; callers size cap from their chunk sizes.
+RRT_DEV uint32_t queue_reserve(const RenderParams& p, uint32_t row, uint32_t chunk, bool keep, uint32_t cap) {
   const unsigned long long mask = __ballot(keep);
-  if (mask == 0) return;
+  if (mask == 0) return 0;
   const int lane = threadIdx.x & 63;
   const int leader = __ffsll((long long)mask) - 1;
   const uint32_t seg = chunk % kSegments;
   uint32_t base = 0;
   if (lane == leader) base = atomicAdd(counter_at(p.a.counters, row, seg), (uint32_t)__popcll(mask));
   base = __shfl(base, leader);
-  if (keep) queue[(size_t)seg * p.a.seg_cap + base + __popcll(mask & ((1ull << lane) - 1ull))] = entry;
+  return seg * cap + base + __popcll(mask & ((1ull << lane) - 1ull));
+}
+RRT_DEV void queue_push(const RenderParams& p, uint32_t* __restrict__ queue, uint32_t row, uint32_t chunk, bool keep,
+                        uint32_t entry) {
+  const uint32_t at = queue_reserve(p, row, chunk, keep, p.a.seg_cap);
+  if (keep) queue[at] = entry;
+}
+RRT_DEV void ray_queue_push(const RenderParams& p, float4* __restrict__ queue, uint32_t row, uint32_t chunk, bool keep,
+                            uint32_t slot, V3 o, V3 d, uint32_t state) {
+  const uint32_t at = queue_reserve(p, row, chunk, keep, p.a.ray_seg_cap);
+  if (keep) {
+    queue[(size_t)at * 2] = f4(o, __uint_as_float(slot));
+    queue[(size_t)at * 2 + 1] = f4(d, __uint_as_float(state));
+  }
 }
 
 // Adds the number of lanes with `pred` to a counter row (no queue behind it).
@@ -150,30 +178,47 @@ RRT_DEV void counter_add(const RenderParams& p, uint32_t row, uint32_t chunk, bo
     atomicAdd(counter_at(p.a.counters, row, chunk % kSegments), (uint32_t)__popcll(mask));
 }
 
-// Consumer side.  queue_scan: the block's first wave scans the row's kSegments counters into LDS
-// (all threads of the block must call it: it synchronises) and returns the queue length.
-// queue_item: the entry stored as item i, found by a search over the scanned counters.
-RRT_DEV uint32_t queue_scan(const RenderParams& p, uint32_t row, uint32_t* prefix /* LDS, kSegments + 1 words */) {
+// Consumer side.  Work is handed out in blocks of G consecutive entries of ONE segment, block j
+// covering entries [j / kSegments * G, +G) of segment j % kSegments.  Walking j upwards therefore
+// visits all segments side by side, which is the order the producer filled them in -- and that
+// order follows the image (slots are laid out tile by tile).  Rays that are in flight together
+// then start close together and share the nodes they fetch; reading segment after segment
+// instead would mix rays from all over the image and halve the L2 hit rate.
+// queue_lengths: the block's first wave loads the row's kSegments counters into LDS (all threads
+// of the block must call it: it synchronises) and returns the longest.
+RRT_DEV uint32_t queue_lengths(const RenderParams& p, uint32_t row, uint32_t* lens /* LDS, kSegments + 1 words */) {
   if (threadIdx.x < kSegments) {
-    uint32_t incl = *counter_at(p.a.counters, row, threadIdx.x);
+    const uint32_t n = *counter_at(p.a.counters, row, threadIdx.x);
+    lens[threadIdx.x] = n;
+    uint32_t m = n;
 #pragma unroll
-    for (int d = 1; d < kSegments; d <<= 1) {
-      const uint32_t up = __shfl_up(incl, d);
-      if ((int)threadIdx.x >= d) incl += up;
-    }
-    prefix[threadIdx.x + 1] = incl;
-    if (threadIdx.x == 0) prefix[0] = 0;
+    for (int d = kSegments / 2; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    if (threadIdx.x == 0) lens[kSegments] = m;
   }
   __syncthreads();
-  return prefix[kSegments];
+  return lens[kSegments];
+}
+// Number of blocks of G entries that cover a queue whose longest segment has `longest` entries.
+RRT_DEV uint32_t queue_blocks(uint32_t longest, uint32_t g) { return kSegments * ((longest + g - 1) / g); }
+// First entry and entry count of block j (count 0: the segment is shorter).
+RRT_DEV const uint32_t* queue_block(const RenderParams& p, const uint32_t* __restrict__ queue, const uint32_t* lens, uint32_t j,
+                                    uint32_t g, uint32_t* count) {
+  const uint32_t seg = j % kSegments, first = j / kSegments * g, len = lens[seg];
+  *count = first < len ? min(g, len - first) : 0u;
+  return queue + (size_t)seg * p.a.seg_cap + first;
 }
 
-RRT_DEV uint32_t queue_item(const RenderParams& p, const uint32_t* __restrict__ queue, const uint32_t* prefix, uint32_t i) {
-  int lo = 0;  // largest s with prefix[s] <= i
-#pragma unroll
-  for (int step = kSegments / 2; step > 0; step >>= 1)
-    if (prefix[lo + step] <= i) lo += step;
-  return queue[(size_t)lo * p.a.seg_cap + (i - prefix[lo])];
+// The analytic shapes, copied to LDS once per block.  A traversing lane looks at them every time
+// a ray arrives, and through the global pointer every field read there is a memory round trip of
+// its own (a dozen per arrival).  The copy is a SceneTables cut off before `lights`: the
+// traversal kernels read nothing beyond.
+constexpr uint32_t kShapeWords = (uint32_t)(offsetof(SceneTables, lights) + 3) / 4;
+#define RRT_DECLARE_SHAPES() __shared__ uint32_t rrt_shape_words[rrt::kShapeWords]
+RRT_DEV const SceneTables* shapes_to_lds(const SceneTables* __restrict__ scene, uint32_t* words) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(scene);
+  for (uint32_t i = threadIdx.x; i < kShapeWords; i += blockDim.x) words[i] = src[i];
+  __syncthreads();
+  return reinterpret_cast<const SceneTables*>(words);
 }
 
 template <bool COUNT>
@@ -214,6 +259,13 @@ RRT_DEV void camera_ray(const CameraParams& cam, uint32_t x, uint32_t y, const R
                       (float)w[8] * d.x + (float)w[9] * d.y + (float)w[10] * d.z));
 }
 
+RRT_DEV const float4* ray_queue_block(const RenderParams& p, const float4* __restrict__ queue, const uint32_t* lens, uint32_t j,
+                                      uint32_t g, uint32_t* count) {
+  const uint32_t seg = j % kSegments, first = j / kSegments * g, len = lens[seg];
+  *count = first < len ? min(g, len - first) : 0u;
+  return queue + ((size_t)seg * p.a.ray_seg_cap + first) * 2;
+}
+
 // ---------------------------------------------------------------- init
 // Every slot of a pixel inside the window enters the first start queue.
 __global__ void __launch_bounds__(256) k_init(RenderParams p) {
@@ -229,14 +281,17 @@ __global__ void __launch_bounds__(256) k_init(RenderParams p) {
 
 // ---------------------------------------------------------------- start
 __global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam, uint32_t parity) {
-  __shared__ uint32_t prefix[kSegments + 1];
-  const uint32_t n = queue_scan(p, row_start(parity), prefix);
-  for (uint32_t chunk = blockIdx.x; chunk * 256 < n; chunk += gridDim.x) {
-    const uint32_t i = chunk * 256 + threadIdx.x;
+  __shared__ uint32_t lens[kSegments + 1];
+  const uint32_t chunks = queue_blocks(queue_lengths(p, row_start(parity), lens), 256);
+  for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+    uint32_t n;
+    const uint32_t* entries = queue_block(p, p.a.q_start[parity], lens, chunk, 256, &n);
+    const uint32_t i = threadIdx.x;
     uint32_t slot = 0;
     bool started = false;
+    V3 org = mk(0.0f, 0.0f, 0.0f), dir = org;
     if (i < n) {
-      const uint32_t entry = queue_item(p, p.a.q_start[parity], prefix, i);
+      const uint32_t entry = entries[i];
       slot = entry & kSlotMask;
       uint32_t x, y, k, sample;
       slot_pixel(p, slot, &x, &y, &k);
@@ -264,18 +319,16 @@ __global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam,
         float4 acc = p.a.accum[slot];
         acc.x += l4.x; acc.y += l4.y; acc.z += l4.z; acc.w += 1.0f;
         p.a.accum[slot] = acc;
-        sample = __float_as_uint(p.a.ray_o[slot].w) + p.n_samples;
+        sample = p.a.sample[slot] + p.n_samples;
       }
       if (sample < p.sample_end) {
         const Rng4 r = rng_block(p.seed, y * p.width + x, sample, 0);
-        V3 org, dir;
         camera_ray(cam, x, y, r, &org, &dir);
-        p.a.ray_o[slot] = f4(org, __uint_as_float(sample));
-        p.a.ray_d[slot] = f4(dir, __uint_as_float(0u));
+        p.a.sample[slot] = sample;
         started = true;
       }
     }
-    queue_push(p, p.a.q_camera, kRowCamera, chunk, started, slot);
+    ray_queue_push(p, p.a.rays_camera, kRowCamera, chunk, started, slot, org, dir, 0u);
     counter_add(p, kRowPaths, chunk, started);
   }
 }
@@ -283,8 +336,8 @@ __global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam,
 // ---------------------------------------------------------------- extend
 // Block size in which a traversal kernel's waves take jobs from the global cursor: large enough
 // that the cursor sees few atomics, small enough that every wave comes back several times.
-RRT_DEV uint32_t grab_size(uint32_t total, uint32_t waves) {
-  const uint32_t g = (total / (4u * waves) + 63u) & ~63u;
+RRT_DEV uint32_t grab_size(uint32_t longest, uint32_t waves) {
+  const uint32_t g = (longest * kSegments / (4u * waves) + 63u) & ~63u;
   return min(max(g, 64u), 1024u);
 }
 
@@ -292,16 +345,26 @@ RRT_DEV uint32_t grab_size(uint32_t total, uint32_t waves) {
 template <bool COUNT>
 struct ExtendJob {
   const RenderParams& p;
-  const uint32_t* prefix_c;
-  const uint32_t* prefix_s;
-  uint32_t n_cont, parity;
-  uint32_t slot;
-  bool cont, hit_surface;
+  const SceneTables* sc;  // LDS copy of the shapes
+  const uint32_t* lens_c;
+  const uint32_t* lens_s;
+  uint32_t blocks_c, grab, parity;
+  const float4* entries;  // of the open block
+  uint32_t slot, state;
+  bool hit_surface;
+  uint32_t out_slot;   // result of the retired job, until the flush
+  bool out_hit;
 
-  RRT_DEV bool begin(uint32_t index, Ray* ray) {
-    cont = index < n_cont;
-    slot = cont ? queue_item(p, p.a.q_cont[parity], prefix_c, index) : queue_item(p, p.a.q_camera, prefix_s, index - n_cont);
-    const float4 o = p.a.ray_o[slot], d = p.a.ray_d[slot];
+  RRT_DEV uint32_t open_block(uint32_t j) {
+    uint32_t n;
+    entries = j < blocks_c ? ray_queue_block(p, p.a.rays_cont[parity], lens_c, j, grab, &n)
+                           : ray_queue_block(p, p.a.rays_camera, lens_s, j - blocks_c, grab, &n);
+    return n;
+  }
+  RRT_DEV bool begin(uint32_t i, Ray* ray) {
+    const float4 o = entries[2 * i], d = entries[2 * i + 1];
+    slot = __float_as_uint(o.w);
+    state = __float_as_uint(d.w);
     ray->o = mk(o);
     ray->d = mk(d);
     ray->tmin = 0.0f;
@@ -311,48 +374,75 @@ struct ExtendJob {
   }
   RRT_DEV bool advance(bool found, const Hit& tri_hit, const RayPre& r, Ray*) {
     Hit h = tri_hit;
-    const SceneTables* sc = p.scene;
     if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
     hit_surface = h.prim >= 0;
-    if (hit_surface) p.a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+    // shade needs the whole ray, start (for a ray that escaped) its direction and state
+    p.a.ray_d[slot] = f4(r.d, __uint_as_float(state));
+    if (hit_surface) {
+      p.a.ray_o[slot] = f4(r.o, 0.0f);
+      p.a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+    }
     return false;
   }
+  RRT_DEV void retire() {
+    out_slot = slot;
+    out_hit = hit_surface;
+  }
+  // Two queues, two atomics: both issued before either result is used.
   RRT_DEV void flush(bool done, uint32_t block) {
-    queue_push(p, p.a.q_shade, kRowShade, block, done && hit_surface, slot);
-    queue_push(p, p.a.q_start[parity ^ 1u], row_start(parity ^ 1u), block, done && !hit_surface, slot | kEscaped);
-    counter_add(p, kRowContRays, block, done && cont);
+    const bool to_shade = done && out_hit, to_start = done && !out_hit;
+    const unsigned long long mask_h = __ballot(to_shade), mask_m = __ballot(to_start);
+    const int lane = threadIdx.x & 63;
+    const int leader_h = mask_h ? __ffsll((long long)mask_h) - 1 : 0, leader_m = mask_m ? __ffsll((long long)mask_m) - 1 : 0;
+    const uint32_t seg = block % kSegments, other = parity ^ 1u;
+    uint32_t base_h = 0, base_m = 0;
+    if (mask_h && lane == leader_h) base_h = atomicAdd(counter_at(p.a.counters, kRowShade, seg), (uint32_t)__popcll(mask_h));
+    if (mask_m && lane == leader_m) base_m = atomicAdd(counter_at(p.a.counters, row_start(other), seg), (uint32_t)__popcll(mask_m));
+    base_h = __shfl(base_h, leader_h);
+    base_m = __shfl(base_m, leader_m);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (to_shade) p.a.q_shade[seg * p.a.seg_cap + base_h + __popcll(mask_h & below)] = out_slot;
+    if (to_start) p.a.q_start[other][seg * p.a.seg_cap + base_m + __popcll(mask_m & below)] = out_slot | kEscaped;
+    counter_add(p, kRowContRays, block, done && block < blocks_c);
   }
 };
 
 template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_extend(RenderParams p, uint32_t parity) {
+__global__ void RRT_TRACE_BOUNDS k_extend(RenderParams p, uint32_t parity) {
   RRT_DECLARE_TRACE_STACK();
-  __shared__ uint32_t prefix_c[kSegments + 1], prefix_s[kSegments + 1];
-  const uint32_t n_cont = queue_scan(p, row_cont(parity), prefix_c);
-  const uint32_t n_cam = queue_scan(p, kRowCamera, prefix_s);
-  const uint32_t total = n_cont + n_cam;
+  RRT_DECLARE_SHAPES();
+  const SceneTables* sc = shapes_to_lds(p.scene, rrt_shape_words);
+  __shared__ uint32_t lens_c[kSegments + 1], lens_s[kSegments + 1];
+  const uint32_t longest_c = queue_lengths(p, row_cont(parity), lens_c);
+  const uint32_t longest_s = queue_lengths(p, kRowCamera, lens_s);
+  const uint32_t grab = grab_size(longest_c + longest_s, gridDim.x * (kTraceBlock / 64));
+  const uint32_t blocks_c = queue_blocks(longest_c, grab);
   TraceCounters ctr = {0, 0};
-  ExtendJob<COUNT> job = {p, prefix_c, prefix_s, n_cont, parity, 0, false, false};
-  trace_stream<false, COUNT>(p.nodes, p.tris, p.scene->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0), total,
-                             grab_size(total, gridDim.x * (kTraceBlock / 64)), job, &ctr, rrt_trace_stack);
+  ExtendJob<COUNT> job = {p, sc, lens_c, lens_s, blocks_c, grab, parity, nullptr, 0, 0, false, 0, false};
+  trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
+                             blocks_c + queue_blocks(longest_s, grab), job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, ctr);
 }
 
 // ---------------------------------------------------------------- shade
 __global__ void __launch_bounds__(256) k_shade(RenderParams p, uint32_t parity) {
-  __shared__ uint32_t prefix[kSegments + 1];
-  const uint32_t n = queue_scan(p, kRowShade, prefix);
+  __shared__ uint32_t lens[kSegments + 1];
+  const uint32_t chunks = queue_blocks(queue_lengths(p, kRowShade, lens), 256);
   const uint32_t next = parity ^ 1u;
-  for (uint32_t chunk = blockIdx.x; chunk * 256 < n; chunk += gridDim.x) {
-  const uint32_t i = chunk * 256 + threadIdx.x;
+  for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+  uint32_t n;
+  const uint32_t* entries = queue_block(p, p.a.q_shade, lens, chunk, 256, &n);
+  const uint32_t i = threadIdx.x;
   uint32_t slot = 0;
   bool active = false, survive = false, has_work = false, has_mis = false, has_light = false;
+  V3 next_o = mk(0.0f, 0.0f, 0.0f), next_d = next_o;
+  uint32_t next_state = 0;
   if (i < n) {
     active = true;
-    slot = queue_item(p, p.a.q_shade, prefix, i);
+    slot = entries[i];
     const float4 o4 = p.a.ray_o[slot], d4 = p.a.ray_d[slot], h4 = p.a.hit[slot];
     const V3 org = mk(o4), dir = mk(d4);
-    const uint32_t sample = __float_as_uint(o4.w), bounce = __float_as_uint(d4.w) >> 1;
+    const uint32_t sample = p.a.sample[slot], bounce = __float_as_uint(d4.w) >> 1;
     V3 beta = mk(1.0f, 1.0f, 1.0f);
     if (bounce > 0) beta = mk(p.a.beta[slot]);
     else p.a.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -427,8 +517,9 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, uint32_t parity) 
         beta = beta / (1.0f - q);
       }
       if (survive) {
-        p.a.ray_o[slot] = f4(offset_ray_origin(s.p, s.ng, bs.wi), o4.w);
-        p.a.ray_d[slot] = f4(bs.wi, __uint_as_float(((bounce + 1) << 1) | (bs.specular ? 1u : 0u)));
+        next_o = offset_ray_origin(s.p, s.ng, bs.wi);
+        next_d = bs.wi;
+        next_state = ((bounce + 1) << 1) | (bs.specular ? 1u : 0u);
         p.a.beta[slot] = f4(beta, 0.0f);
       }
     }
@@ -436,7 +527,7 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, uint32_t parity) 
     // without pending light the running sum is unchanged since its last clamp: nothing to do
     if (has_work) p.a.sh_c[slot] = f4(light_c, __uint_as_float(flags));
   }
-  queue_push(p, p.a.q_cont[next], row_cont(next), chunk, survive, slot);
+  ray_queue_push(p, p.a.rays_cont[next], row_cont(next), chunk, survive, slot, next_o, next_d, next_state);
   queue_push(p, p.a.q_start[next], row_start(next), chunk, active && !survive, slot);
   queue_push(p, p.a.q_shadow, kRowShadow, chunk, has_work, slot);
   counter_add(p, kRowBounces, chunk, active);
@@ -450,7 +541,10 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, uint32_t parity) 
 // the clamp; all by one lane, so the sum keeps the order of the reference's loop body.
 struct ConnectJob {
   const RenderParams& p;
-  const uint32_t* prefix;
+  const SceneTables* sc;  // LDS copy of the shapes
+  const uint32_t* lens;
+  uint32_t grab;
+  const uint32_t* entries;  // of the open block
   uint32_t slot, flags;
   int stage;  // the ray in flight: 1 light sample, 2 escape ray
   int own, light_quad;
@@ -459,18 +553,12 @@ struct ConnectJob {
 
   RRT_DEV bool next_ray(Ray* ray) {
     if (stage == 0 && (flags & kHasLightRay)) {
-      const float4 o = p.a.sh_o[slot], d = p.a.sh_d[slot];
       // two things may not occlude by identity: the surface the ray leaves (a triangle, quad or
       // plane cannot be hit twice by a ray that starts on it) and the sampled light's own quad
-      own = __float_as_int(p.a.hit[slot].x);
-      if (own >= p.scene->n_tris + p.scene->n_rects + p.scene->n_planes) own = -1;  // spheres keep their t > 1e-4 guard
-      light_quad = __float_as_int(d.w);
-      far = o.w;
-      ray->o = mk(o);
-      ray->d = mk(d);
+      if (own >= sc->n_tris + sc->n_rects + sc->n_planes) own = -1;  // spheres keep their t > 1e-4 guard
       ray->tmin = 0.0f;
       ray->tmax = fminf(far, kTriTMax);
-      ray->skip = own < p.scene->n_tris ? own : -1;
+      ray->skip = own < sc->n_tris ? own : -1;
       stage = 1;
       return true;
     }
@@ -492,39 +580,57 @@ struct ConnectJob {
     p.a.radiance[slot] = l4;
     return false;
   }
-  RRT_DEV bool begin(uint32_t index, Ray* ray) {
-    slot = queue_item(p, p.a.q_shadow, prefix, index);
+  RRT_DEV uint32_t open_block(uint32_t j) {
+    uint32_t n;
+    entries = queue_block(p, p.a.q_shadow, lens, j, grab, &n);
+    return n;
+  }
+  RRT_DEV bool begin(uint32_t i, Ray* ray) {
+    slot = entries[i];
+    // everything the light-sample ray needs in one round trip, whether or not the entry has one
     c4 = p.a.sh_c[slot];
-    flags = __float_as_uint(c4.w);
     l4 = p.a.radiance[slot];
+    const float4 o = p.a.sh_o[slot], d = p.a.sh_d[slot];
+    own = __float_as_int(p.a.hit[slot].x);
+    flags = __float_as_uint(c4.w);
+    light_quad = __float_as_int(d.w);
+    far = o.w;
+    ray->o = mk(o);
+    ray->d = mk(d);
     stage = 0;
     return next_ray(ray);
   }
   RRT_DEV bool advance(bool found, const Hit&, const RayPre& r, Ray* ray) {
-    const SceneTables* sc = p.scene;
     bool occluded = found;
     if (!occluded && sc->n_rects + sc->n_planes + sc->n_spheres > 0) {
       Hit h;
       occluded = intersect_others<true>(sc, r, far, own, light_quad, &h);
     }
     if (!occluded) {
-      const float4 c = stage == 1 ? c4 : p.a.mis_c[slot];
+      // (not `stage == 1 ? c4 : mis_c[slot]`: a conditional between two lvalues selects between their
+      // addresses, which takes the address of a member and sends the whole job to scratch memory)
+      float4 c = c4;
+      if (stage != 1) c = p.a.mis_c[slot];
       l4.x += c.x; l4.y += c.y; l4.z += c.z;
     }
     return next_ray(ray);
   }
+  RRT_DEV void retire() {}
   RRT_DEV void flush(bool, uint32_t) {}
 };
 
 template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams p) {
+__global__ void RRT_TRACE_BOUNDS k_connect(RenderParams p) {
   RRT_DECLARE_TRACE_STACK();
-  __shared__ uint32_t prefix[kSegments + 1];
-  const uint32_t n = queue_scan(p, kRowShadow, prefix);
+  RRT_DECLARE_SHAPES();
+  const SceneTables* sc = shapes_to_lds(p.scene, rrt_shape_words);
+  __shared__ uint32_t lens[kSegments + 1];
+  const uint32_t longest = queue_lengths(p, kRowShadow, lens);
+  const uint32_t grab = grab_size(longest, gridDim.x * (kTraceBlock / 64));
   TraceCounters ctr = {0, 0};
-  ConnectJob job = {p, prefix, 0, 0, 0, -1, -1, 0.0f, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
-  trace_stream<true, COUNT>(p.nodes, p.tris, p.scene->n_tris > 0, counter_at(p.a.counters, kRowWorkConnect, 0), n,
-                            grab_size(n, gridDim.x * (kTraceBlock / 64)), job, &ctr, rrt_trace_stack);
+  ConnectJob job = {p, sc, lens, grab, nullptr, 0, 0, 0, -1, -1, 0.0f, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+  trace_stream<true, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkConnect, 0),
+                            queue_blocks(longest, grab), job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, ctr);
 }
 
@@ -579,11 +685,15 @@ struct IntersectJob {
   const float* org_dir;
   int32_t* prim_id;
   float* t_out;
-  uint32_t index;
+  uint32_t n, base, index;
 
+  RRT_DEV uint32_t open_block(uint32_t j) {
+    base = j * 256u;
+    return min(256u, n - base);
+  }
   RRT_DEV bool begin(uint32_t i, Ray* ray) {
-    index = i;
-    const float* r = org_dir + (size_t)i * 6;
+    index = base + i;
+    const float* r = org_dir + (size_t)index * 6;
     ray->o = mk(r[0], r[1], r[2]);
     ray->d = mk(r[3], r[4], r[5]);
     ray->tmin = 0.0f;
@@ -600,29 +710,35 @@ struct IntersectJob {
     t_out[index] = h.prim >= 0 ? h.t : 0.0f;
     return false;
   }
+  RRT_DEV void retire() {}
   RRT_DEV void flush(bool, uint32_t) {}
 };
 
-__global__ void __launch_bounds__(kTraceBlock) k_intersect(const BvhNode* nodes, const TriIsect* tris,
+__global__ void RRT_TRACE_BOUNDS k_intersect(const BvhNode* nodes, const TriIsect* tris,
                                                            const SceneTables* sc, const float* __restrict__ org_dir,
                                                            uint32_t n, int32_t* prim_id, float* t_out, uint32_t* work_cursor) {
   RRT_DECLARE_TRACE_STACK();
+  RRT_DECLARE_SHAPES();
+  sc = shapes_to_lds(sc, rrt_shape_words);
   TraceCounters ctr = {0, 0};
-  IntersectJob job = {tris, sc, org_dir, prim_id, t_out, 0};
-  trace_stream<false, false>(nodes, tris, sc->n_tris > 0, work_cursor, n, grab_size(n, gridDim.x * (kTraceBlock / 64)), job,
-                             &ctr, rrt_trace_stack);
+  IntersectJob job = {tris, sc, org_dir, prim_id, t_out, n, 0, 0};
+  trace_stream<false, false>(nodes, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, job, &ctr, rrt_trace_stack);
 }
 
 struct OccludedJob {
   const SceneTables* sc;
   const float* odt;
   uint8_t* out;
-  uint32_t index;
+  uint32_t n, base, index;
   float far;
 
+  RRT_DEV uint32_t open_block(uint32_t j) {
+    base = j * 256u;
+    return min(256u, n - base);
+  }
   RRT_DEV bool begin(uint32_t i, Ray* ray) {
-    index = i;
-    const float* r = odt + (size_t)i * 7;
+    index = base + i;
+    const float* r = odt + (size_t)index * 7;
     far = r[6];
     ray->o = mk(r[0], r[1], r[2]);
     ray->d = mk(r[3], r[4], r[5]);
@@ -640,17 +756,19 @@ struct OccludedJob {
     out[index] = occluded ? 1 : 0;
     return false;
   }
+  RRT_DEV void retire() {}
   RRT_DEV void flush(bool, uint32_t) {}
 };
 
-__global__ void __launch_bounds__(kTraceBlock) k_occluded(const BvhNode* nodes, const TriIsect* tris,
+__global__ void RRT_TRACE_BOUNDS k_occluded(const BvhNode* nodes, const TriIsect* tris,
                                                           const SceneTables* sc, const float* __restrict__ odt,
                                                           uint32_t n, uint8_t* out, uint32_t* work_cursor) {
   RRT_DECLARE_TRACE_STACK();
+  RRT_DECLARE_SHAPES();
+  sc = shapes_to_lds(sc, rrt_shape_words);
   TraceCounters ctr = {0, 0};
-  OccludedJob job = {sc, odt, out, 0, 0.0f};
-  trace_stream<true, false>(nodes, tris, sc->n_tris > 0, work_cursor, n, grab_size(n, gridDim.x * (kTraceBlock / 64)), job, &ctr,
-                            rrt_trace_stack);
+  OccludedJob job = {sc, odt, out, n, 0, 0, 0.0f};
+  trace_stream<true, false>(nodes, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, job, &ctr, rrt_trace_stack);
 }
 
 }  // namespace rrt

@@ -15,30 +15,45 @@ struct Hit {
 
 constexpr float kTriTMax = 1000.0f;  // objects/triangle.rs:164-171
 
-// Traversal stack: the first kLdsDepth entries of every lane live in LDS, laid out
-// [entry][thread] so that the 64 lanes of a wave hit 64 consecutive words (no bank
-// conflicts); deeper entries -- rare -- spill to a per-lane array in scratch memory.
+// Traversal stack of (node reference, entry distance) pairs: the first kLdsDepth entries of every
+// lane live in LDS, laid out [entry][thread] so that the lanes of a wave touch consecutive words
+// (no bank conflicts); deeper entries -- rare -- spill to a per-lane array in scratch memory.
 constexpr int kTraceBlock = 256;   // threads per block of every kernel that traverses
 #ifndef RRT_LDS_STACK_DEPTH
-#define RRT_LDS_STACK_DEPTH 12  // measured: 12 beats 0 (all in scratch) by 15% and 24 by 3%
+#define RRT_LDS_STACK_DEPTH 12
 #endif
 constexpr int kLdsDepth = RRT_LDS_STACK_DEPTH;
-constexpr int kSpillDepth = 96 - kLdsDepth;  // 96 entries in all: deeper than any tree the builder makes (SAH depth <= 40 + median levels)
-#define RRT_DECLARE_TRACE_STACK() __shared__ int rrt_trace_stack[(rrt::kLdsDepth > 0 ? rrt::kLdsDepth : 1) * rrt::kTraceBlock]
+constexpr int kStackDepth = 192;   // a 4-wide node pushes up to 3 entries: trees up to 63 inner levels (checked at upload)
+constexpr int kSpillDepth = kStackDepth - kLdsDepth;
+#define RRT_DECLARE_TRACE_STACK() __shared__ int2 rrt_trace_stack[(rrt::kLdsDepth > 0 ? rrt::kLdsDepth : 1) * rrt::kTraceBlock]
+// The LDS part is addressed through a pointer that names its address space.  Through a generic
+// pointer the compiler folds "LDS or scratch?" into a select between two generic addresses and
+// issues flat loads, which take the slow path for both and wait on every counter.
+// The accesses are volatile for the same reason: a volatile load is never merged with the scratch one.
+typedef volatile __attribute__((address_space(3))) int* LdsStackWordPtr;
 
 // The stack pointer is a plain local of the traversal loop, and the spill array a local of its
 // own: as members of one struct next to a dynamically indexed array they would all be placed in
 // scratch memory, and every push and pop would reload the stack pointer from there.
-#define RRT_STACK_PUSH(v)                                                        \
+#define RRT_STACK_PUSH(ref, t)                                                   \
   do {                                                                           \
-    if (kLdsDepth > 0 && sp < kLdsDepth) lds[sp * kTraceBlock] = (v);            \
-    else spill[min(sp - kLdsDepth, kSpillDepth - 1)] = (v);                      \
+    if (kLdsDepth > 0 && sp < kLdsDepth) {                                       \
+      const LdsStackWordPtr w_ = lds + sp * (2 * kTraceBlock);                   \
+      w_[0] = (ref);                                                             \
+      w_[1] = __float_as_int(t);                                                 \
+    } else {                                                                     \
+      spill[min(sp - kLdsDepth, kSpillDepth - 1)] = make_int2((ref), __float_as_int(t)); \
+    }                                                                            \
     ++sp;                                                                        \
   } while (0)
 #define RRT_STACK_POP(dst)                                                       \
   do {                                                                           \
     --sp;                                                                        \
-    if (kLdsDepth > 0 && sp < kLdsDepth) (dst) = lds[sp * kTraceBlock];          \
+    if (kLdsDepth > 0 && sp < kLdsDepth) {                                       \
+      const LdsStackWordPtr w_ = lds + sp * (2 * kTraceBlock);                   \
+      (dst).x = w_[0];                                                           \
+      (dst).y = w_[1];                                                           \
+    }                                                                            \
     else (dst) = spill[min(sp - kLdsDepth, kSpillDepth - 1)];                    \
   } while (0)
 
@@ -72,31 +87,53 @@ RRT_DEV float slab(const RayPre& r, float mnx, float mny, float mnz, float mxx, 
   return tn <= tf * 1.0000005f ? tn : INFINITY;
 }
 
-// Moeller-Trumbore.  Accepts t in (tmin, tmax); barycentrics u (vertex 1), v (vertex 2).
-RRT_DEV bool intersect_tri(const TriIsect* __restrict__ tris, int index, const RayPre& r, float tmin, float tmax,
-                           float* t_out, float* u_out, float* v_out) {
+// Moeller-Trumbore on an already loaded record.  Accepts t in (tmin, tmax); barycentrics u
+// (vertex 1), v (vertex 2).  No early exits: a branch on the determinant would let the compiler
+// sink the load of v0 below it, and a leaf would pay two dependent memory round trips per triangle.
+struct TriRec {
+  float4 v0, e1, e2;
+};
+RRT_DEV TriRec load_tri(const TriIsect* __restrict__ tris, int index) {
   const float4* rec = reinterpret_cast<const float4*>(tris + index);
-  const float4 a = rec[0], b = rec[1], c = rec[2];
-  const V3 v0 = mk(a), e1 = mk(b), e2 = mk(c);
+  TriRec t;
+  t.v0 = rec[0];
+  t.e1 = rec[1];
+  t.e2 = rec[2];
+  return t;
+}
+RRT_DEV bool intersect_tri(const TriRec& rec, const RayPre& r, float tmin, float tmax, float* t_out, float* u_out,
+                           float* v_out) {
+  const V3 v0 = mk(rec.v0), e1 = mk(rec.e1), e2 = mk(rec.e2);
   const V3 pvec = cross(r.d, e2);
   const float det = dot(e1, pvec);
-  if (det == 0.0f) return false;
   const float inv_det = 1.0f / det;
   const V3 tvec = r.o - v0;
   const float u = dot(tvec, pvec) * inv_det;
   const V3 qvec = cross(tvec, e1);
   const float v = dot(r.d, qvec) * inv_det;
   const float t = dot(e2, qvec) * inv_det;
-  if (u < 0.0f || v < 0.0f || u + v > 1.0f || !(t > tmin) || !(t < tmax)) return false;
   *t_out = t;
   *u_out = u;
   *v_out = v;
-  return true;
+  // det == 0 gives inf or NaN above; every comparison is written so that NaN fails it
+  return det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > tmin && t < tmax;
 }
 
 struct TraceCounters {
   uint32_t nodes, tris;
 };
+
+#ifdef RRT_PHASE_CLOCKS
+// Diagnostic build only: wave-cycles per phase of trace_stream, printed by rrt_get_stats.
+//   0 refill cycles  1 node-phase cycles  2 leaf-phase cycles  3 node iterations  4 leaf iterations
+//   5 lanes stepping (sum over node iterations)  6 lanes at a leaf (sum over leaf iterations)  7 refills
+//   8 total wave cycles  9 triangle-loop trips
+__device__ unsigned long long rrt_phase_dbg[32];  // closest-hit launches in [0, 16), any-hit in [16, 32)
+#define RRT_CLK() __builtin_readcyclecounter()
+#define RRT_DBG_ADD(i, v) do { if (lane == 0) dbg[i] += (v); } while (0)
+#else
+#define RRT_DBG_ADD(i, v) do { } while (0)
+#endif
 
 struct Ray {
   V3 o, d;
@@ -111,21 +148,24 @@ struct Ray {
 // state machine; a lane whose ray is finished hands in its result and takes the next job as soon as
 // kRefillQuorum lanes are free, so the wave stays mostly full until the queue is empty.
 //
-// Job indices come from a global cursor in blocks of `grab` (one atomic per block per wave), which
-// also balances the load between waves.  A job is a type with
-//   bool begin(uint32_t index, Ray* ray)       first ray of job `index`; false: the job needs no ray
+// Jobs come in numbered blocks; a wave takes the next block number from a global cursor (one atomic
+// per block), which also balances the load between waves.  A job is a type with
+//   uint32_t open_block(uint32_t j)            wave-uniform: makes block j current, returns its job count
+//   bool begin(uint32_t i, Ray* ray)           first ray of job i of the current block; false: no ray needed
 //   bool advance(bool found, const Hit& hit, const RayPre& r, Ray* ray)
 //                                              a ray is done (triangles only: the job looks at the
 //                                              analytic shapes itself); true: `ray` is its next one
-//   void flush(bool done, uint32_t block)      wave-collective; `done` lanes completed a job taken
-//                                              from index block `block` since the last flush
+//   void retire()                              the job is complete: set its result aside for flush (the
+//                                              lane's begin() for its next job runs before the flush)
+//   void flush(bool done, uint32_t block)      wave-collective; `done` lanes retired a job taken
+//                                              from block `block` since the last flush
 // Closest hit (ANY = false) or any hit (ANY = true) with t in (tmin, tmax).
 //
 // Inside the loop the lanes at inner nodes step together until kLeafQuorum of the travelling lanes
 // have reached a leaf, then those test their triangles (the while-while scheme, without making
 // every lane wait for the last straggler to arrive at a leaf).
 #ifndef RRT_REFILL_QUORUM
-#define RRT_REFILL_QUORUM 16
+#define RRT_REFILL_QUORUM 32
 #endif
 #ifndef RRT_LEAF_FRACTION
 #define RRT_LEAF_FRACTION 4  // leaf phase when 1/4 of the travelling lanes are at a leaf
@@ -133,11 +173,12 @@ struct Ray {
 
 template <bool ANY, bool COUNT, class Job>
 RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __restrict__ tris, bool has_tris,
-                          uint32_t* work_cursor, uint32_t total, uint32_t grab, Job& job, TraceCounters* ctr,
-                          int* lds_stack) {
+                          uint32_t* work_cursor, uint32_t n_blocks, Job& job, TraceCounters* ctr,
+                          int2* lds_stack) {
   enum { kIdle = 0, kTravelling = 1, kArrived = 2, kJobDone = 3 };
-  int* lds = lds_stack + threadIdx.x;  // this thread's column: entry e at lds[e * kTraceBlock]
-  int spill[kSpillDepth];
+  // this thread's column: the two words of entry e at lds[e * 2 * kTraceBlock + {0, 1}]
+  const LdsStackWordPtr lds = (LdsStackWordPtr)lds_stack + 2 * threadIdx.x;
+  int2 spill[kSpillDepth];
   const int lane = threadIdx.x & 63;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   uint32_t cursor = 0, end = 0, block = 0;  // wave-uniform: the index block being handed out
@@ -153,6 +194,12 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
   hit.t = INFINITY;
   hit.u = hit.v = 0.0f;
   bool found = false;
+#ifdef RRT_PHASE_CLOCKS
+  unsigned long long dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long clk2 = 0;
+  const unsigned long long clk_begin = RRT_CLK();
+  unsigned long long clk = clk_begin;
+#endif
 
 #define RRT_START_RAY(ray)                                   \
   do {                                                       \
@@ -167,52 +214,93 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
     cur = 0;                                                 \
     state = has_tris ? kTravelling : kArrived;               \
   } while (0)
+  // entries pushed before the ray found its current hit may lie beyond it: those are skipped unread
 #define RRT_POP_OR_ARRIVE()                                  \
   do {                                                       \
-    if (sp > 0) RRT_STACK_POP(cur);                          \
-    else state = kArrived;                                   \
+    state = kArrived;                                        \
+    while (sp > 0) {                                         \
+      int2 e_;                                               \
+      RRT_STACK_POP(e_);                                     \
+      if (ANY || __int_as_float(e_.y) < tmax) {              \
+        cur = e_.x;                                          \
+        state = kTravelling;                                 \
+        break;                                               \
+      }                                                      \
+    }                                                        \
   } while (0)
 
   for (;;) {
+    // a finished ray: the job may have another one; otherwise its result waits for the flush below
+    bool done = false;
+    uint32_t done_block = 0;
     if (state == kArrived) {
       Ray ray;
       if (job.advance(found, hit, r, &ray)) RRT_START_RAY(ray);
       else state = kJobDone;
     }
-    // hand in finished jobs, one index block at a time
-    unsigned long long done_mask = __ballot(state == kJobDone);
-    while (done_mask) {
-      const uint32_t b = __shfl(my_block, __ffsll((long long)done_mask) - 1);
-      const bool mine = state == kJobDone && my_block == b;
-      job.flush(mine, b);
-      if (mine) state = kIdle;
-      done_mask &= ~__ballot(mine);
+    if (state == kJobDone) {
+      done = true;
+      done_block = my_block;
+      job.retire();
+      state = kIdle;
     }
-    // refill idle lanes (a second pass when the first one ran into the end of an index block)
-    for (int pass = 0; pass < 2; ++pass) {
-      const unsigned long long idle_mask = __ballot(state == kIdle);
+#ifdef RRT_PHASE_CLOCKS
+    { clk2 = RRT_CLK(); RRT_DBG_ADD(10, clk2 - clk); }
+#endif
+    // refill idle lanes: only issues the loads of the new jobs -- their rays are looked at after
+    // the flush, so that the flush's atomics and these loads are in flight together (further
+    // passes when one ran into the end of a block or met an empty one)
+    bool fresh = false, fresh_ray = false;
+    Ray pending;
+    pending.o = pending.d = mk(0.0f, 0.0f, 0.0f);
+    pending.tmin = pending.tmax = 0.0f;
+    pending.skip = -1;
+    for (int pass = 0; pass < 4; ++pass) {
+      const unsigned long long idle_mask = __ballot(state == kIdle && !fresh);
       if (idle_mask == 0 || exhausted) break;
       if (cursor >= end) {
         uint32_t g = 0;
-        if (lane == 0) g = atomicAdd(work_cursor, grab);
+        if (lane == 0) g = atomicAdd(work_cursor, 1u);
         g = __shfl(g, 0);
-        if (g >= total) {
+        if (g >= n_blocks) {
           exhausted = true;
           break;
         }
-        cursor = g;
-        end = min(g + grab, total);
-        block = g / grab;
+        block = g;
+        cursor = 0;
+        end = job.open_block(g);
+        if (end == 0) continue;
       }
       const uint32_t index = cursor + (uint32_t)__popcll(idle_mask & lanes_below);
-      if (state == kIdle && index < end) {
+      if (state == kIdle && !fresh && index < end) {
         my_block = block;
-        Ray ray;
-        if (job.begin(index, &ray)) RRT_START_RAY(ray);
-        else state = kJobDone;
+        fresh = true;
+        fresh_ray = job.begin(index, &pending);
       }
       cursor = min(end, cursor + (uint32_t)__popcll(idle_mask));
     }
+#ifdef RRT_PHASE_CLOCKS
+    { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(11, now - clk2); clk2 = now; }
+#endif
+    // hand in finished jobs, one index block at a time
+    unsigned long long done_mask = __ballot(done);
+    while (done_mask) {
+      const uint32_t b = __shfl(done_block, __ffsll((long long)done_mask) - 1);
+      const bool mine = done && done_block == b;
+      job.flush(mine, b);
+      if (mine) done = false;
+      done_mask &= ~__ballot(mine);
+    }
+#ifdef RRT_PHASE_CLOCKS
+    { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(12, now - clk2); clk2 = now; }
+#endif
+    if (fresh) {
+      if (fresh_ray) RRT_START_RAY(pending);
+      else state = kJobDone;
+    }
+#ifdef RRT_PHASE_CLOCKS
+    { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(0, now - clk); RRT_DBG_ADD(7, 1); clk = now; }
+#endif
     if (__ballot(state == kTravelling) == 0) {
       if (__ballot(state != kIdle) == 0 && exhausted) break;
       continue;
@@ -221,40 +309,66 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
     // ---- traversal until enough lanes have arrived to make a refill worth its cost
     for (;;) {
       for (;;) {
+        RRT_DBG_ADD(5, __popcll(__ballot(state == kTravelling && cur >= 0)));
         if (state == kTravelling && cur >= 0) {
           const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-          const float4 n0 = np[0], n1 = np[1], n2 = np[2];
-          const int4 n3 = reinterpret_cast<const int4*>(np)[3];
+          const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+          const int4 ch = reinterpret_cast<const int4*>(np)[6];
           if (COUNT) ctr->nodes++;
-          const float tl = slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tmin, tmax);
-          const float tr = slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tmin, tmax);
-          const bool hl = tl < INFINITY, hr = tr < INFINITY;
-          if (hl && hr) {
-            const bool left_first = tl <= tr;
-            const int farc = left_first ? n3.y : n3.x;
-            RRT_STACK_PUSH(farc);
-            cur = left_first ? n3.x : n3.y;
-          } else if (hl) {
-            cur = n3.x;
-          } else if (hr) {
-            cur = n3.y;
+          float t0 = slab(r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, tmin, tmax);
+          float t1 = slab(r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, tmin, tmax);
+          float t2 = slab(r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, tmin, tmax);
+          float t3 = slab(r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, tmin, tmax);
+          int c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+          // sort the four by entry distance (misses are +inf and end up last)
+#define RRT_CSWAP(ta, ca, tb, cb)                   \
+  do {                                              \
+    const bool sw_ = tb < ta;                       \
+    const float tt_ = sw_ ? ta : tb;                \
+    const int cc_ = sw_ ? ca : cb;                  \
+    ta = sw_ ? tb : ta;                             \
+    ca = sw_ ? cb : ca;                             \
+    tb = tt_;                                       \
+    cb = cc_;                                       \
+  } while (0)
+          RRT_CSWAP(t0, c0, t1, c1);
+          RRT_CSWAP(t2, c2, t3, c3);
+          RRT_CSWAP(t0, c0, t2, c2);
+          RRT_CSWAP(t1, c1, t3, c3);
+          RRT_CSWAP(t1, c1, t2, c2);
+#undef RRT_CSWAP
+          if (t0 < INFINITY) {
+            // farthest first, so that the nearest comes off the stack first
+            if (t3 < INFINITY) RRT_STACK_PUSH(c3, t3);
+            if (t2 < INFINITY) RRT_STACK_PUSH(c2, t2);
+            if (t1 < INFINITY) RRT_STACK_PUSH(c1, t1);
+            cur = c0;
           } else {
             RRT_POP_OR_ARRIVE();
           }
         }
         const unsigned long long inner = __ballot(state == kTravelling && cur >= 0);
         const unsigned long long at_leaf = __ballot(state == kTravelling && cur < 0);
+        RRT_DBG_ADD(3, 1);
         if (inner == 0 || RRT_LEAF_FRACTION * __popcll(at_leaf) >= __popcll(inner | at_leaf)) break;
       }
+#ifdef RRT_PHASE_CLOCKS
+      { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(1, now - clk); clk = now;
+        RRT_DBG_ADD(4, 1); RRT_DBG_ADD(6, __popcll(__ballot(state == kTravelling && cur < 0))); }
+#endif
       if (state == kTravelling && cur < 0) {
         // leaf: ~cur = first << 2 | (count - 1)
         const int code = ~cur;
         const int first = code >> 2, cnt = (code & 3) + 1;
+        // the next triangle's record is in flight while this one is tested
+        TriRec rec = load_tri(tris, first);
         for (int i = 0; i < cnt; ++i) {
           const int ti = first + i;
+          const TriRec cur_rec = rec;
+          if (i + 1 < cnt) rec = load_tri(tris, ti + 1);
           if (COUNT) ctr->tris++;
           float t, u, v;
-          if (ti != skip && intersect_tri(tris, ti, r, tmin, tmax, &t, &u, &v)) {
+          if (intersect_tri(cur_rec, r, tmin, tmax, &t, &u, &v) && ti != skip) {
             found = true;
             if (ANY) break;
             tmax = t;
@@ -267,10 +381,19 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
         if (ANY && found) state = kArrived;
         else RRT_POP_OR_ARRIVE();
       }
+#ifdef RRT_PHASE_CLOCKS
+      { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(2, now - clk); clk = now; }
+#endif
       const unsigned long long arrived = __ballot(state == kArrived);
       if (__ballot(state == kTravelling) == 0 || __popcll(arrived) >= RRT_REFILL_QUORUM) break;
     }
   }
+#ifdef RRT_PHASE_CLOCKS
+  if (lane == 0) {
+    dbg[8] = RRT_CLK() - clk_begin;
+    for (int i = 0; i < 16; ++i) atomicAdd(&rrt_phase_dbg[(ANY ? 16 : 0) + i], dbg[i]);
+  }
+#endif
 #undef RRT_START_RAY
 #undef RRT_POP_OR_ARRIVE
 }

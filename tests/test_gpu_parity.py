@@ -255,4 +255,4 @@ def test_stats_count_what_happened(rrt, cornell, gpu_ctx):
     assert st.paths <= st.rays_extend <= 3 * st.paths
     assert 0 < st.path_bounces <= st.rays_extend
     assert 0 < st.rays_shadow <= st.path_bounces
-    assert st.bvh_nodes > 1000 and st.bvh_bytes > 4014 * 96
+    assert st.bvh_nodes > 4014 // 12 and st.bvh_bytes > 4014 * 96

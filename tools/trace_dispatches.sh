@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/trace_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp 16 --cpu-seconds 0 --no-calibrate "$@" > $OUT/bench.json || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp ${SPP:-16} --cpu-seconds 0 --no-calibrate "$@" > $OUT/bench.json || exit 1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/*/*_kernel_trace.csv")[0]
