@@ -45,9 +45,9 @@ standin = _load("rust_raytracer_amd.standin", "rust-raytracer_amd/standin.py")
 rrdist = _load("rust_raytracer_amd.distributed", "rust-raytracer_amd/distributed.py")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-# algorithmic bytes per ray: 64 B per BVH node visited (two child boxes + links), 36 B per triangle
-# tested (nine f32 positions), 32 B ray in, 16 B hit out
-NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 64, 36, 32, 16
+# algorithmic bytes per ray: 112 B per BVH node visited (four child boxes of six f32 + four links), 36 B per
+# triangle tested (nine f32 positions), 32 B ray in, 16 B hit out
+NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 112, 36, 32, 16
 
 
 def load_buddha(width, height):
@@ -60,7 +60,9 @@ def load_buddha(width, height):
         scene.set_material(0, material)
         mesh = "happy-buddha.obj"
     else:
-        pos, nrm = standin.happy_buddha_standin()
+        # RRT_BENCH_MESH_DIVISOR: diagnostic only (coarser stand-in = smaller working set); the bench line is quoted at 1
+        div = int(os.environ.get("RRT_BENCH_MESH_DIVISOR", "1"))
+        pos, nrm = standin.happy_buddha_standin() if div == 1 else standin.happy_buddha_standin(966 // div, 563 // div)
         scene = rr.Scene.load_from_folder_with_mesh(folder, pos, nrm, material)
         mesh = "generated stand-in"
     camera = rr.Camera.from_settings(rs, width, height)

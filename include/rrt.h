@@ -184,8 +184,12 @@ void* rrt_film_device_ptr(rrt_ctx* ctx);
 
 /* Renders sample indices [sample_begin, sample_end) of every pixel in the crop
  * window and adds them to the film: the pixel x max_samples loop of render_work
- * (src/renderer.rs:191-207) with trace (src/tracer.rs:24) inside.  Returns when
- * the work has been enqueued on the context's stream; rrt_synchronize waits. */
+ * (src/renderer.rs:191-207) with trace (src/tracer.rs:24) inside.  The work
+ * runs on the context's stream; how many rounds of kernels it takes depends on
+ * the paths, so the call reads a counter back every few rounds and returns once
+ * the last round has been enqueued and the queues are known to be empty.  The
+ * film kernel may still be running then: rrt_synchronize waits for it, and work
+ * enqueued on the same stream afterwards is ordered behind it. */
 int rrt_render(rrt_ctx* ctx, const rrt_settings* settings, uint32_t sample_begin, uint32_t sample_end);
 int rrt_synchronize(rrt_ctx* ctx);
 
@@ -206,9 +210,9 @@ int rrt_occluded(rrt_ctx* ctx, const float* org_dir_tmax, uint32_t n, uint8_t* h
 
 /* Options. */
 enum {
-  RRT_OPT_TIMING = 1,          /* 1: time each kernel with HIP events (the host waits at the end of every batch) */
-  RRT_OPT_BATCH_SAMPLES = 2,   /* samples per pixel kept in flight per batch (0 = automatic) */
-  RRT_OPT_MAX_SLOTS = 3,       /* upper bound on paths in flight per batch (sizes the path-state arrays) */
+  RRT_OPT_TIMING = 1,          /* 1: time each kernel with HIP events (the host waits at the end of every pass) */
+  RRT_OPT_BATCH_SAMPLES = 2,   /* path slots per pixel (each works through its share of the samples; 0 = automatic) */
+  RRT_OPT_MAX_SLOTS = 3,       /* upper bound on paths in flight (sizes the path-state arrays; at most 2^30) */
   RRT_OPT_COUNT_TRAVERSAL = 4  /* 1: count nodes_visited / tris_tested (slower kernels; for calibration runs) */
 };
 int rrt_set_option(rrt_ctx* ctx, int option, int64_t value);

@@ -161,15 +161,54 @@ struct Ray {
 //                                              from block `block` since the last flush
 // Closest hit (ANY = false) or any hit (ANY = true) with t in (tmin, tmax).
 //
-// Inside the loop the lanes at inner nodes step together until kLeafQuorum of the travelling lanes
-// have reached a leaf, then those test their triangles (the while-while scheme, without making
-// every lane wait for the last straggler to arrive at a leaf).
+// Two step schemes.  Closest hit: the lanes at inner nodes step together until 1 in
+// RRT_LEAF_FRACTION of the travelling lanes have reached a leaf, then those test their triangles
+// (the while-while scheme, without making every lane wait for the last straggler to arrive at a
+// leaf).  Any hit, whose step has less arithmetic in it: every trip steps every lane once, node or
+// triangle, with both kinds of load in flight together.  Measured: each scheme loses 15-20% on
+// the other kind of ray.
 #ifndef RRT_REFILL_QUORUM
 #define RRT_REFILL_QUORUM 32
 #endif
 #ifndef RRT_LEAF_FRACTION
-#define RRT_LEAF_FRACTION 4  // leaf phase when 1/4 of the travelling lanes are at a leaf
+#define RRT_LEAF_FRACTION 4
 #endif
+
+// One inner-node step of a lane: the four child boxes against the ray, nearest child next, the
+// other children that were hit onto the stack (farthest first, so the nearest comes off first).
+#define RRT_CSWAP(ta, ca, tb, cb)                   \
+  do {                                              \
+    const bool sw_ = tb < ta;                       \
+    const float tt_ = sw_ ? ta : tb;                \
+    const int cc_ = sw_ ? ca : cb;                  \
+    ta = sw_ ? tb : ta;                             \
+    ca = sw_ ? cb : ca;                             \
+    tb = tt_;                                       \
+    cb = cc_;                                       \
+  } while (0)
+#define RRT_NODE_STEP(lx, ly, lz, hx, hy, hz, ch)                                        \
+  do {                                                                                   \
+    if (COUNT) ctr->nodes++;                                                             \
+    float t0 = slab(r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, tmin, tmax);                  \
+    float t1 = slab(r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, tmin, tmax);                  \
+    float t2 = slab(r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, tmin, tmax);                  \
+    float t3 = slab(r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, tmin, tmax);                  \
+    int c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;                                      \
+    /* sort the four by entry distance (misses are +inf and end up last) */              \
+    RRT_CSWAP(t0, c0, t1, c1);                                                           \
+    RRT_CSWAP(t2, c2, t3, c3);                                                           \
+    RRT_CSWAP(t0, c0, t2, c2);                                                           \
+    RRT_CSWAP(t1, c1, t3, c3);                                                           \
+    RRT_CSWAP(t1, c1, t2, c2);                                                           \
+    if (t0 < INFINITY) {                                                                 \
+      if (t3 < INFINITY) RRT_STACK_PUSH(c3, t3);                                         \
+      if (t2 < INFINITY) RRT_STACK_PUSH(c2, t2);                                         \
+      if (t1 < INFINITY) RRT_STACK_PUSH(c1, t1);                                         \
+      cur = c0;                                                                          \
+    } else {                                                                             \
+      RRT_POP_OR_ARRIVE();                                                               \
+    }                                                                                    \
+  } while (0)
 
 template <bool ANY, bool COUNT, class Job>
 RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __restrict__ tris, bool has_tris,
@@ -307,85 +346,109 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
     }
 
     // ---- traversal until enough lanes have arrived to make a refill worth its cost
-    for (;;) {
+    if (ANY) {
+      // One step per lane per trip: a lane at an inner node tests its four child boxes, a lane at
+      // a leaf tests ONE of the leaf's triangles.  Both kinds of load are issued before either is
+      // waited for, so a trip costs one memory round trip whatever the mix of lanes -- the round
+      // trips, not the arithmetic, are what the kernel's time is made of.
       for (;;) {
-        RRT_DBG_ADD(5, __popcll(__ballot(state == kTravelling && cur >= 0)));
-        if (state == kTravelling && cur >= 0) {
+        const bool at_node = state == kTravelling && cur >= 0;
+        const bool at_leaf = state == kTravelling && cur < 0;
+        float4 lx, ly, lz, hx, hy, hz;
+        int4 ch;
+        TriRec rec;
+        int ti = 0;
+        lx = ly = lz = hx = hy = hz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        ch = make_int4(0, 0, 0, 0);
+        rec.v0 = rec.e1 = rec.e2 = lx;
+        if (at_node) {
           const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-          const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
-          const int4 ch = reinterpret_cast<const int4*>(np)[6];
-          if (COUNT) ctr->nodes++;
-          float t0 = slab(r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, tmin, tmax);
-          float t1 = slab(r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, tmin, tmax);
-          float t2 = slab(r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, tmin, tmax);
-          float t3 = slab(r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, tmin, tmax);
-          int c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-          // sort the four by entry distance (misses are +inf and end up last)
-#define RRT_CSWAP(ta, ca, tb, cb)                   \
-  do {                                              \
-    const bool sw_ = tb < ta;                       \
-    const float tt_ = sw_ ? ta : tb;                \
-    const int cc_ = sw_ ? ca : cb;                  \
-    ta = sw_ ? tb : ta;                             \
-    ca = sw_ ? cb : ca;                             \
-    tb = tt_;                                       \
-    cb = cc_;                                       \
-  } while (0)
-          RRT_CSWAP(t0, c0, t1, c1);
-          RRT_CSWAP(t2, c2, t3, c3);
-          RRT_CSWAP(t0, c0, t2, c2);
-          RRT_CSWAP(t1, c1, t3, c3);
-          RRT_CSWAP(t1, c1, t2, c2);
-#undef RRT_CSWAP
-          if (t0 < INFINITY) {
-            // farthest first, so that the nearest comes off the stack first
-            if (t3 < INFINITY) RRT_STACK_PUSH(c3, t3);
-            if (t2 < INFINITY) RRT_STACK_PUSH(c2, t2);
-            if (t1 < INFINITY) RRT_STACK_PUSH(c1, t1);
-            cur = c0;
-          } else {
-            RRT_POP_OR_ARRIVE();
-          }
+          lx = np[0]; ly = np[1]; lz = np[2]; hx = np[3]; hy = np[4]; hz = np[5];
+          ch = reinterpret_cast<const int4*>(np)[6];
         }
-        const unsigned long long inner = __ballot(state == kTravelling && cur >= 0);
-        const unsigned long long at_leaf = __ballot(state == kTravelling && cur < 0);
+        if (at_leaf) {
+          ti = (~cur) >> 2;  // leaf: ~cur = first << 2 | (count - 1)
+          rec = load_tri(tris, ti);
+        }
+        // keeps the compiler from fusing each load with its use below, which would put the two
+        // round trips one after the other
+        asm volatile("" ::: "memory");
         RRT_DBG_ADD(3, 1);
-        if (inner == 0 || RRT_LEAF_FRACTION * __popcll(at_leaf) >= __popcll(inner | at_leaf)) break;
-      }
-#ifdef RRT_PHASE_CLOCKS
-      { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(1, now - clk); clk = now;
-        RRT_DBG_ADD(4, 1); RRT_DBG_ADD(6, __popcll(__ballot(state == kTravelling && cur < 0))); }
-#endif
-      if (state == kTravelling && cur < 0) {
-        // leaf: ~cur = first << 2 | (count - 1)
-        const int code = ~cur;
-        const int first = code >> 2, cnt = (code & 3) + 1;
-        // the next triangle's record is in flight while this one is tested
-        TriRec rec = load_tri(tris, first);
-        for (int i = 0; i < cnt; ++i) {
-          const int ti = first + i;
-          const TriRec cur_rec = rec;
-          if (i + 1 < cnt) rec = load_tri(tris, ti + 1);
+        if (at_node) {
+          RRT_NODE_STEP(lx, ly, lz, hx, hy, hz, ch);
+        }
+        if (at_leaf) {
           if (COUNT) ctr->tris++;
           float t, u, v;
-          if (intersect_tri(cur_rec, r, tmin, tmax, &t, &u, &v) && ti != skip) {
+          if (intersect_tri(rec, r, tmin, tmax, &t, &u, &v) && ti != skip) {
             found = true;
-            if (ANY) break;
             tmax = t;
             hit.prim = ti;
             hit.t = t;
             hit.u = u;
             hit.v = v;
           }
+          const int left = (~cur) & 3;  // triangles of this leaf still to test
+          if (ANY && found) state = kArrived;
+          else if (left > 0) cur = ~(((ti + 1) << 2) | (left - 1));
+          else RRT_POP_OR_ARRIVE();
         }
-        if (ANY && found) state = kArrived;
-        else RRT_POP_OR_ARRIVE();
+        const unsigned long long arrived = __ballot(state == kArrived);
+        if (__ballot(state == kTravelling) == 0 || __popcll(arrived) >= RRT_REFILL_QUORUM) break;
       }
 #ifdef RRT_PHASE_CLOCKS
-      { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(2, now - clk); clk = now; }
+      { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(1, now - clk); clk = now; }
 #endif
-      const unsigned long long arrived = __ballot(state == kArrived);
-      if (__ballot(state == kTravelling) == 0 || __popcll(arrived) >= RRT_REFILL_QUORUM) break;
+    } else {
+      for (;;) {
+        for (;;) {
+          RRT_DBG_ADD(5, __popcll(__ballot(state == kTravelling && cur >= 0)));
+          if (state == kTravelling && cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(nodes + cur);
+            const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+            const int4 ch = reinterpret_cast<const int4*>(np)[6];
+            RRT_NODE_STEP(lx, ly, lz, hx, hy, hz, ch);
+          }
+          const unsigned long long inner = __ballot(state == kTravelling && cur >= 0);
+          const unsigned long long at_leaf = __ballot(state == kTravelling && cur < 0);
+          RRT_DBG_ADD(3, 1);
+          if (inner == 0 || RRT_LEAF_FRACTION * __popcll(at_leaf) >= __popcll(inner | at_leaf)) break;
+        }
+#ifdef RRT_PHASE_CLOCKS
+        { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(1, now - clk); clk = now;
+          RRT_DBG_ADD(4, 1); RRT_DBG_ADD(6, __popcll(__ballot(state == kTravelling && cur < 0))); }
+#endif
+        if (state == kTravelling && cur < 0) {
+          // leaf: ~cur = first << 2 | (count - 1)
+          const int code = ~cur;
+          const int first = code >> 2, cnt = (code & 3) + 1;
+          // the next triangle's record is in flight while this one is tested
+          TriRec rec = load_tri(tris, first);
+          for (int i = 0; i < cnt; ++i) {
+            const int ti = first + i;
+            const TriRec cur_rec = rec;
+            if (i + 1 < cnt) rec = load_tri(tris, ti + 1);
+            if (COUNT) ctr->tris++;
+            float t, u, v;
+            if (intersect_tri(cur_rec, r, tmin, tmax, &t, &u, &v) && ti != skip) {
+              found = true;
+              if (ANY) break;
+              tmax = t;
+              hit.prim = ti;
+              hit.t = t;
+              hit.u = u;
+              hit.v = v;
+            }
+          }
+          if (ANY && found) state = kArrived;
+          else RRT_POP_OR_ARRIVE();
+        }
+#ifdef RRT_PHASE_CLOCKS
+        { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(2, now - clk); clk = now; }
+#endif
+        const unsigned long long arrived = __ballot(state == kArrived);
+        if (__ballot(state == kTravelling) == 0 || __popcll(arrived) >= RRT_REFILL_QUORUM) break;
+      }
     }
   }
 #ifdef RRT_PHASE_CLOCKS
