@@ -528,7 +528,12 @@ int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* sd) {
       double n[3];
       cross3(l.v1, l.v2, n);
       norm3(n, d.normal);
-      d.area = (float)(l.v2[0] * l.v2[0] + l.v2[1] * l.v2[1] + l.v2[2] * l.v2[2]);  // |side_b|^2, rectangle.rs:131-133
+      const double aa = l.v1[0] * l.v1[0] + l.v1[1] * l.v1[1] + l.v1[2] * l.v1[2];
+      const double bb = l.v2[0] * l.v2[0] + l.v2[1] * l.v2[1] + l.v2[2] * l.v2[2];
+      const double ab = l.v1[0] * l.v2[0] + l.v1[1] * l.v2[1] + l.v1[2] * l.v2[2];
+      d.area = (float)bb;  // |side_b|^2, rectangle.rs:131-133
+      d.skew_a = (float)(ab / aa);
+      d.skew_b = (float)(ab / bb);
       for (uint32_t r = 0; r < sd->n_rects; ++r)
         if (sd->rects[r].light == (int32_t)i) d.rect = (int)r;
     } else if (l.kind == RRT_LIGHT_DISTANT) {

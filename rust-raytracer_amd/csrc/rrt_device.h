@@ -94,6 +94,7 @@ struct DeviceLight {
   float v0[3], v1[3], v2[3];  // see rrt_light
   float normal[3];            // area: normalize(a x b)
   float area;                 // area: |side_b|^2 (objects/rectangle.rs:131-133)
+  float skew_a, skew_b;       // area: (a.b)/|a|^2 and (a.b)/|b|^2, zero for a rectangle proper
   int rect;                   // area: index of its quad in rects[], -1 if none
 };
 

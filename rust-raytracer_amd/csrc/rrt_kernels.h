@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, uint32_t parity) 
         float pdf_s;
         bsdf_eval(s, m, ls.wi, &f, &pdf_s);
         f = f * fabsf(dot(ls.wi, s.ns));
-        if (!is_zero(f)) {
+        if (!is_zero(f) && !(prim < sc->n_tris && own_triangle_occludes(p.tris, prim, s, ls.wi))) {
           const float w = ls.delta ? 1.0f : power_heuristic(ls.pdf, pdf_s);
           light_c = beta * f * ls.li * (w * n_lights / ls.pdf);
           // check_light_visible (src/renderer.rs:277-295): from the surface point towards the

@@ -21,6 +21,7 @@ struct Surface {
   V3 wo;
   int material;
   int light;       // index of the area light this object belongs to, or -1
+  float lift;      // triangles: signed height of p over the triangle's plane along ng; 0 when p lies in the plane
 };
 
 // ---------------------------------------------------------------- surface interaction
@@ -58,9 +59,33 @@ RRT_DEV Surface surface_triangle(const TriIsect* __restrict__ tris, const TriSha
   const V3 q1 = p_hit - dot(p_hit - p1, n1) * n1;
   const V3 q2 = p_hit - dot(p_hit - p2, n2) * n2;
   const V3 sp = b0 * q0 + b1 * q1 + b2 * q2;
-  s.p = dot(sp - p_hit, ng_raw) > 0.0f ? sp : p_hit;
-  s.ng = dot(ng_raw, s.ns) < 0.0f ? -ng_raw : ng_raw;
+  const float height = dot(sp - p_hit, ng_raw);
+  const bool flipped = dot(ng_raw, s.ns) < 0.0f;
+  s.p = height > 0.0f ? sp : p_hit;
+  s.ng = flipped ? -ng_raw : ng_raw;
+  s.lift = height > 0.0f ? (flipped ? -height : height) : 0.0f;
   return s;
+}
+
+// The reference's visibility ray (src/renderer.rs:277-295) starts at the lifted point.  When the
+// lift took the point to one side of its own triangle and the ray heads for the other, the ray
+// crosses that triangle -- at a distance of the order of the lift, which f64 resolves and the
+// reference therefore counts as an occluder (self-shadowing of a smoothed mesh).  The device's
+// visibility ray leaves its own triangle out of the traversal (in f32 a ray that starts in the
+// plane would hit it at random), so the crossing is decided here, from the lift itself.
+// A lift below 1e-5 of the triangle's size is taken for zero: on a flat-shaded face the exact lift
+// is 0, f64 computes ~1e-17 (less than the ray's 1e-9 head start, so no hit), f32 computes ~1e-7.
+RRT_DEV bool own_triangle_occludes(const TriIsect* __restrict__ tris, int prim, const Surface& s, V3 wi) {
+  const float c = dot(wi, s.ng);
+  if (s.lift == 0.0f || c * s.lift >= 0.0f) return false;
+  const float4* ti = reinterpret_cast<const float4*>(tris + prim);
+  const V3 p0 = mk(ti[0]), e1 = mk(ti[1]), e2 = mk(ti[2]);
+  if (s.lift * s.lift <= 1e-10f * fmaxf(norm2(e1), norm2(e2))) return false;
+  const V3 x = s.p + wi * (-s.lift / c);
+  const V3 w = x - p0, n = cross(e1, e2);
+  const float inv = 1.0f / dot(n, n);
+  const float u = dot(cross(w, e2), n) * inv, v = dot(cross(e1, w), n) * inv;
+  return u >= 0.0f && v >= 0.0f && u + v <= 1.0f;
 }
 
 // Rectangle / Plane / Sphere (objects/rectangle.rs:85-100, plane.rs:59-79, sphere.rs:36-104).
@@ -68,6 +93,7 @@ RRT_DEV Surface surface_other(const SceneTables* __restrict__ sc, int prim, floa
   Surface s;
   s.wo = -dir;
   s.light = -1;
+  s.lift = 0.0f;
   int k = prim - sc->n_tris;
   if (k < sc->n_rects) {
     const DeviceRect& q = sc->rects[k];
@@ -422,9 +448,14 @@ RRT_DEV LightSample sample_light(const SceneTables* __restrict__ sc, const uint8
     r.wi = d / r.dist;
     const V3 n = mk(l.normal);
     const float cos_l = dot(n, -r.wi);
-    // Rectangle::pdf re-intersects the quad along wi (objects/rectangle.rs:113-129);
-    // the sampled point is that intersection unless the ray is parallel to it
-    r.pdf = fabsf(cos_l) < 1e-9f ? 0.0f : dist2 / (fabsf(cos_l) * l.area);
+    // Rectangle::pdf re-intersects the quad along wi (objects/rectangle.rs:113-129).  The sampled
+    // point is that intersection unless the ray is parallel to the quad -- but the intersection
+    // routine accepts a point by its projections onto the two sides (rectangle.rs:82-93), and for
+    // sides that are not perpendicular the projections of pos + u a + v b are u + v (a.b)/|a|^2 and
+    // v + u (a.b)/|b|^2: where either leaves [0, 1] the pdf is 0 and the sample is dropped.
+    const float proj_a = fmaf(u1, l.skew_a, u0), proj_b = fmaf(u0, l.skew_b, u1);
+    const bool on_quad = proj_a >= 0.0f && proj_a <= 1.0f && proj_b >= 0.0f && proj_b <= 1.0f;
+    r.pdf = (fabsf(cos_l) < 1e-9f || !on_quad) ? 0.0f : dist2 / (fabsf(cos_l) * l.area);
     r.li = cos_l > 0.0f ? mk(l.intensity) : mk(0.0f, 0.0f, 0.0f);
     r.skip = l.rect >= 0 ? sc->n_tris + l.rect : -1;
   } else if (l.kind == RRT_LIGHT_DISTANT) {

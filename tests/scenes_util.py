@@ -76,3 +76,22 @@ def ray_set(rrt, oracle, rs, n_primary, seed):
     second = bounce_rays(oracle, first, rng)
     rays = np.concatenate([primary, first, second])
     return rays.astype(np.float32).astype(np.float64)
+
+
+def buddha_scene(rrt, n_theta=242, n_v=141):
+    """scenes/buddha (environment + distant + 3 area lights, thin lens, microfacet plastic) with the
+    closed-form stand-in mesh at a resolution the CPU oracle handles in seconds (4 * n_theta *
+    (n_v - ...) ~ 68 k triangles by default): deep enough a tree that traversal stacks outgrow their
+    LDS part."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rust_raytracer_amd.standin", os.path.join(root, "rust-raytracer_amd", "standin.py"))
+    standin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(standin)
+    folder = os.path.join(rrt.SCENES, "buddha")
+    rs = rrt.load_render_settings(folder)
+    material = rrt.make_material(rrt.MAT_PLASTIC, kd=(0.6, 0.6, 0.6), ks=(1.0, 1.0, 1.0), roughness=0.27, ior=1.5)
+    pos, nrm = standin.happy_buddha_standin(n_theta, n_v)
+    scene = rrt.Scene.load_from_folder_with_mesh(folder, pos, nrm, material)
+    return scene, rs
