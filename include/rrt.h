@@ -182,6 +182,20 @@ int rrt_film_clear(rrt_ctx* ctx);
 int rrt_film_download(rrt_ctx* ctx, float* host_sum_rgbw);
 void* rrt_film_device_ptr(rrt_ctx* ctx);
 
+/* The reconstruction filter of Film::new (src/film.rs:59-132: the `film.filter_method` and
+ * `film.filter_radius` keys of render_settings.yaml, src/main.rs:286-287).  With a method other
+ * than NONE every finished sample is splatted over the pixels within `radius` of its film position
+ * with the weights of the 16 x 16 table (Film::write_bucket_pixels, src/film.rs:169-215); with
+ * NONE (the default) it lands in its own pixel with weight 1 and `radius` is ignored.  Applies to
+ * the rrt_render calls that follow. */
+enum { RRT_FILTER_NONE = 0, RRT_FILTER_GAUSSIAN = 1, RRT_FILTER_MITCHELL = 2 };
+int rrt_set_filter(rrt_ctx* ctx, uint32_t method, double radius);
+
+/* The tone map of Film::merge_bucket_pixels_to_image_buffer (src/film.rs:233-249) on the device:
+ * sum / weight through the XYZ -> sRGB matrix and the sRGB transfer curve, truncated to 8 bits;
+ * a pixel without weight is black.  host_rgb8 receives [height][width][3]. */
+int rrt_film_tonemap(rrt_ctx* ctx, uint8_t* host_rgb8);
+
 /* Renders sample indices [sample_begin, sample_end) of every pixel in the crop
  * window and adds them to the film: the pixel x max_samples loop of render_work
  * (src/renderer.rs:191-207) with trace (src/tracer.rs:24) inside.  The work

@@ -38,6 +38,7 @@ def lib():
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_destroy.restype = None
         L.orc_set_camera.argtypes = [C.c_void_p, dp, dp, C.c_double, C.c_double]
+        L.orc_set_filter.argtypes = [C.c_void_p, C.c_uint32, C.c_double]
         L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_void_p, C.POINTER(OracleStats)]
         L.orc_trace_one.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, dp]
@@ -103,6 +104,10 @@ class Oracle:
         c2w = np.ascontiguousarray(camera.camera_to_world, dtype=np.float64)
         rc = self._lib.orc_set_camera(self._h, r2c.ctypes.data_as(dp), c2w.ctypes.data_as(dp), camera.aperture,
                                       camera.focal_distance)
+        assert rc == 0
+
+    def set_filter(self, method, radius=0.0):
+        rc = self._lib.orc_set_filter(self._h, method, radius)
         assert rc == 0
 
     def render(self, settings, sample_begin, sample_end, threads=0, bucket=(128, 128), film=None):

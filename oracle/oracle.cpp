@@ -1072,6 +1072,10 @@ struct orc_ctx {
   std::vector<Aabb> boxes;
   Bvh bvh;
   Camera camera;
+  // Film::new (src/film.rs:59-132): reconstruction filter
+  uint32_t filter_method = RRT_FILTER_NONE;
+  double filter_radius = 0.0;
+  std::vector<double> filter_table;  // 16 x 16
 };
 
 namespace {
@@ -1495,6 +1499,51 @@ int orc_set_camera(orc_ctx* ctx, const double raster_to_camera[16], const double
   return RRT_OK;
 }
 
+namespace {
+// src/film.rs:326-333
+double evaluate_gaussian(double px, double py, double radius, double alpha) {
+  const double expv = std::exp(-alpha * radius * radius);
+  const double x = std::max(std::exp(-alpha * px * px) - expv, 0.0);
+  const double y = std::max(std::exp(-alpha * py * py) - expv, 0.0);
+  return x * y;
+}
+// src/film.rs:340-358
+double evaluate_mitchell_1d(double input) {
+  const double b = 0.33, c = 0.33;
+  const double x = std::fabs(2.0 * input);
+  if (x > 1.0)
+    return ((-b - 6.0 * c) * x * x * x + (6.0 * b + 30.0 * c) * x * x + (-12.0 * b - 48.0 * c) * x + (8.0 * b + 24.0 * c)) *
+           (1.0 / 6.0);
+  return ((12.0 - 9.0 * b - 6.0 * c) * x * x * x + (-18.0 + 12.0 * b + 6.0 * c) * x * x + (6.0 - 2.0 * b)) * (1.0 / 6.0);
+}
+// src/film.rs:335-338
+double evaluate_mitchell(double px, double py, double radius) {
+  const double inv = 1.0 / radius;
+  return evaluate_mitchell_1d(px * inv) * evaluate_mitchell_1d(py * inv);
+}
+}  // namespace
+
+// Film::new's filter table (src/film.rs:87-112); GAUSSIAN_ALPHA = 1.5 (src/film.rs:17)
+int orc_set_filter(orc_ctx* ctx, uint32_t method, double radius) {
+  if (!ctx || method > RRT_FILTER_MITCHELL) return RRT_E_INVALID;
+  if (method != RRT_FILTER_NONE && !(radius > 0.0)) return RRT_E_INVALID;
+  ctx->filter_method = method;
+  ctx->filter_table.clear();
+  if (method == RRT_FILTER_NONE) {
+    ctx->filter_radius = 0.0;
+    return RRT_OK;
+  }
+  ctx->filter_radius = radius;
+  const int n = 16;
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < n; ++x) {
+      const double xp = (x + 0.5) * radius / n, yp = (y + 0.5) * radius / n;
+      ctx->filter_table.push_back(method == RRT_FILTER_GAUSSIAN ? evaluate_gaussian(xp, yp, radius, 1.5)
+                                                                : evaluate_mitchell(xp, yp, radius));
+    }
+  return RRT_OK;
+}
+
 int orc_render(orc_ctx* ctx, const rrt_settings* st, uint32_t sample_begin, uint32_t sample_end, uint32_t bucket_w,
                uint32_t bucket_h, uint32_t threads, double* film, orc_stats* stats) {
   if (!ctx || !st || !film || !ctx->camera.set || sample_end < sample_begin || !bucket_w || !bucket_h)
@@ -1539,22 +1588,47 @@ int orc_render(orc_ctx* ctx, const rrt_settings* st, uint32_t sample_begin, uint
             r.radiance[0] = l.x; r.radiance[1] = l.y; r.radiance[2] = l.z;
             samples.push_back(r);
           }
-      // write_bucket_pixels, filter none (src/film.rs:157-167)
-      const uint32_t bw = b.x1 - b.x0, bh = b.y1 - b.y0;
+      // the bucket's pixel raster reaches a filter radius beyond its samples (src/film.rs:289-300;
+      // a negative start saturates to 0 in the cast to u32)
+      const double fr = ctx->filter_radius;
+      const uint32_t px0 = (uint32_t)std::max(0.0, std::floor((double)b.x0 - 0.5 - fr));
+      const uint32_t py0 = (uint32_t)std::max(0.0, std::floor((double)b.y0 - 0.5 - fr));
+      const uint32_t px1 = std::min((uint32_t)std::ceil((double)b.x1 + 0.5 + fr), st->width);
+      const uint32_t py1 = std::min((uint32_t)std::ceil((double)b.y1 + 0.5 + fr), st->height);
+      const uint32_t bw = px1 - px0, bh = py1 - py0;
       std::vector<BPixel> px((size_t)bw * bh, BPixel{0, {0, 0, 0}});
+      // write_bucket_pixels (src/film.rs:150-219)
       for (const SampleResult& r : samples) {
-        const uint32_t ix = (uint32_t)r.p_film[0] - b.x0, iy = (uint32_t)r.p_film[1] - b.y0;
-        if (ix >= bw || iy >= bh) continue;
-        BPixel& p = px[(size_t)iy * bw + ix];
-        p.sum_weight += 1.0;
-        for (int k = 0; k < 3; ++k) p.sum_radiance[k] += r.radiance[k];
+        if (ctx->filter_method == RRT_FILTER_NONE) {
+          const uint32_t ix = (uint32_t)r.p_film[0] - px0, iy = (uint32_t)r.p_film[1] - py0;
+          if (ix >= bw || iy >= bh) continue;
+          BPixel& p = px[(size_t)iy * bw + ix];
+          p.sum_weight += 1.0;
+          for (int k = 0; k < 3; ++k) p.sum_radiance[k] += r.radiance[k];
+          continue;
+        }
+        const int x_min = (int)std::ceil(r.p_film[0] - fr), y_min = (int)std::ceil(r.p_film[1] - fr);
+        const int x_max = (int)std::floor(r.p_film[0] + fr), y_max = (int)std::floor(r.p_film[1] + fr);
+        const double n = 16.0;
+        for (int x = x_min; x <= x_max; ++x)
+          for (int y = y_min; y <= y_max; ++y) {
+            if (x < 0 || y < 0 || x >= (int)st->width || y >= (int)st->height) continue;
+            const size_t fx = (size_t)std::min(std::floor(std::fabs(((double)x - r.p_film[0]) * (1.0 / fr) * n)), n - 1.0);
+            const size_t fy = (size_t)std::min(std::floor(std::fabs(((double)y - r.p_film[1]) * (1.0 / fr) * n)), n - 1.0);
+            const double w = ctx->filter_table[fy * 16 + fx];
+            const uint32_t ix = (uint32_t)x - px0, iy = (uint32_t)y - py0;
+            if (ix >= bw || iy >= bh) continue;
+            BPixel& p = px[(size_t)iy * bw + ix];
+            p.sum_weight += w;
+            for (int k = 0; k < 3; ++k) p.sum_radiance[k] += r.radiance[k] * w;
+          }
       }
       // merge_bucket_pixels_to_image_buffer (src/film.rs:221-231)
       std::lock_guard<std::mutex> lock(film_mutex);
       for (uint32_t iy = 0; iy < bh; ++iy)
         for (uint32_t ix = 0; ix < bw; ++ix) {
           const BPixel& p = px[(size_t)iy * bw + ix];
-          double* out = film + 4 * ((size_t)(b.y0 + iy) * st->width + (b.x0 + ix));
+          double* out = film + 4 * ((size_t)(py0 + iy) * st->width + (px0 + ix));
           out[0] += p.sum_radiance[0];
           out[1] += p.sum_radiance[1];
           out[2] += p.sum_radiance[2];

@@ -54,6 +54,8 @@ int orc_set_camera(orc_ctx* ctx, const double raster_to_camera[16], const double
 /* render + render_work + trace + Film (src/renderer.rs:92-211, src/film.rs:150-251):
  * `threads` workers pull bucket_w x bucket_h buckets from a mutex-guarded queue;
  * film_sum_rgbw is double [height][width][4], added to. */
+/* Film::new's reconstruction filter (src/film.rs:59-132): method is one of RRT_FILTER_*. */
+int orc_set_filter(orc_ctx* ctx, uint32_t method, double radius);
 int orc_render(orc_ctx* ctx, const rrt_settings* settings, uint32_t sample_begin, uint32_t sample_end,
                uint32_t bucket_w, uint32_t bucket_h, uint32_t threads, double* film_sum_rgbw, orc_stats* stats);
 

@@ -69,6 +69,11 @@ struct rrt_ctx {
   uint32_t state_slots = 0, state_depth = 0;
   bool state_has_mis = false;
 
+  // reconstruction filter
+  uint32_t filter_method = RRT_FILTER_NONE;
+  double filter_radius = 0.0;
+  float* d_filter_table = nullptr;
+
   DeviceStats* d_stats = nullptr;
   uint32_t* d_work = nullptr;     // job cursor of the rrt_intersect / rrt_occluded launches
   uint32_t* h_pending = nullptr;  // pinned: the two queue-length rows read back between iterations
@@ -348,7 +353,8 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
     burst = (uint32_t)std::min<uint64_t>(4, max_iterations - it);
   }
   if ((rc = record_begin(ctx, 4)) != RRT_OK) return rc;
-  hipLaunchKernelGGL(k_film, dim3(grid_for(p.n_tiles * 64)), dim3(kBlock), 0, ctx->stream, p);
+  // with a reconstruction filter the samples went into the film as their paths ended
+  if (!p.filter_table) hipLaunchKernelGGL(k_film, dim3(grid_for(p.n_tiles * 64)), dim3(kBlock), 0, ctx->stream, p);
   hipLaunchKernelGGL(k_pass_stats, dim3(1), dim3(64), 0, ctx->stream, p);
   if ((rc = record_end(ctx)) != RRT_OK) return rc;
   HIP_TRY(ctx, hipGetLastError());
@@ -404,6 +410,7 @@ void rrt_destroy(rrt_ctx* ctx) {
   if (ctx->film_owned) (void)hipFree(ctx->d_film);
   (void)hipFree(ctx->d_stats);
   (void)hipFree(ctx->d_work);
+  (void)hipFree(ctx->d_filter_table);
   if (ctx->h_pending) (void)hipHostFree(ctx->h_pending);
   for (EventPair& e : ctx->events) {
     (void)hipEventDestroy(e.begin);
@@ -650,6 +657,69 @@ int rrt_film_download(rrt_ctx* ctx, float* host) {
 
 void* rrt_film_device_ptr(rrt_ctx* ctx) { return ctx ? ctx->d_film : nullptr; }
 
+namespace {
+// src/film.rs:326-358; GAUSSIAN_ALPHA = 1.5 (src/film.rs:17)
+double evaluate_gaussian(double px, double py, double radius, double alpha) {
+  const double expv = std::exp(-alpha * radius * radius);
+  return std::max(std::exp(-alpha * px * px) - expv, 0.0) * std::max(std::exp(-alpha * py * py) - expv, 0.0);
+}
+double evaluate_mitchell_1d(double input) {
+  const double b = 0.33, c = 0.33;
+  const double x = std::fabs(2.0 * input);
+  if (x > 1.0)
+    return ((-b - 6.0 * c) * x * x * x + (6.0 * b + 30.0 * c) * x * x + (-12.0 * b - 48.0 * c) * x + (8.0 * b + 24.0 * c)) *
+           (1.0 / 6.0);
+  return ((12.0 - 9.0 * b - 6.0 * c) * x * x * x + (-18.0 + 12.0 * b + 6.0 * c) * x * x + (6.0 - 2.0 * b)) * (1.0 / 6.0);
+}
+}  // namespace
+
+int rrt_set_filter(rrt_ctx* ctx, uint32_t method, double radius) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (method > RRT_FILTER_MITCHELL) return fail(ctx, RRT_E_INVALID, "unknown filter method");
+  if (method == RRT_FILTER_NONE) {
+    ctx->filter_method = method;
+    ctx->filter_radius = 0.0;  // src/film.rs:110-112
+    return RRT_OK;
+  }
+  if (!(radius > 0.0) || radius > 64.0) return fail(ctx, RRT_E_INVALID, "filter radius out of range");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  float table[256];
+  const int n = 16;  // filter_table_size, src/film.rs:88
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < n; ++x) {
+      const double xp = (x + 0.5) * radius / n, yp = (y + 0.5) * radius / n;
+      table[y * n + x] = (float)(method == RRT_FILTER_GAUSSIAN
+                                     ? evaluate_gaussian(xp, yp, radius, 1.5)
+                                     : evaluate_mitchell_1d(xp / radius) * evaluate_mitchell_1d(yp / radius));
+    }
+  if (!ctx->d_filter_table && (rc = dev_alloc(ctx, &ctx->d_filter_table, 256)) != RRT_OK) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // a render still using the old table
+  HIP_TRY(ctx, hipMemcpy(ctx->d_filter_table, table, sizeof(table), hipMemcpyHostToDevice));
+  ctx->filter_method = method;
+  ctx->filter_radius = radius;
+  return RRT_OK;
+}
+
+int rrt_film_tonemap(rrt_ctx* ctx, uint8_t* host_rgb8) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!host_rgb8) return fail(ctx, RRT_E_INVALID, "null destination");
+  if (!ctx->d_film) return fail(ctx, RRT_E_STATE, "no film");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  const size_t n = (size_t)ctx->film_w * ctx->film_h;
+  uint8_t* d_rgb = nullptr;
+  if ((rc = dev_alloc(ctx, &d_rgb, n * 3)) != RRT_OK) return rc;
+  hipLaunchKernelGGL(k_tonemap, dim3(grid_for((uint32_t)n)), dim3(kBlock), 0, ctx->stream,
+                     reinterpret_cast<const float4*>(ctx->d_film), (uint32_t)n, d_rgb);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(host_rgb8, d_rgb, n * 3, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_rgb);
+  if (e != hipSuccess) return fail(ctx, RRT_E_DEVICE, std::string("tone map: ") + hipGetErrorString(e));
+  return RRT_OK;
+}
+
 int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint32_t sample_end) {
   if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
   if (!s) return fail(ctx, RRT_E_INVALID, "null settings");
@@ -701,6 +771,8 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
   p.tiles_x = tiles_x;
   p.depth_limit = s->depth_limit;
   p.clamp = (float)s->clamp;
+  p.filter_table = ctx->filter_method != RRT_FILTER_NONE ? ctx->d_filter_table : nullptr;
+  p.filter_radius = ctx->filter_radius;
   for (uint64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_batch) {
     p.tile_begin = (uint32_t)t0;
     p.n_tiles = (uint32_t)std::min<uint64_t>(tiles_per_batch, total_tiles - t0);

@@ -121,6 +121,8 @@ struct RenderParams {
   uint32_t n_slots;                 // n_tiles * 64 * K
   uint32_t depth_limit;
   float clamp;
+  const float* filter_table;  // 16 x 16 weights, or null: every sample lands in its own pixel with weight 1
+  double filter_radius;
 };
 
 RRT_DEV uint32_t* counter_at(uint32_t* counters, uint32_t row, uint32_t seg) {
@@ -279,6 +281,32 @@ __global__ void __launch_bounds__(256) k_init(RenderParams p) {
   queue_push(p, p.a.q_start[0], row_start(0), blockIdx.x, live, slot | kFresh);
 }
 
+// Film::write_bucket_pixels with a reconstruction filter (src/film.rs:169-215): the sample at film
+// position (fx, fy) adds weight * L to every pixel within the radius.  Pixels are shared between
+// slots here, so the sums are atomic (their order, and with it the last bits of the film, varies
+// from run to run).  The pixel range and table index are computed in f64 like the original: the
+// film position has more significant bits than an f32 holds.
+RRT_DEV void splat_filtered(const RenderParams& p, double fx, double fy, float lr, float lg, float lb) {
+  const double r = p.filter_radius;
+  const int x_min = (int)ceil(fx - r), y_min = (int)ceil(fy - r);
+  const int x_max = (int)floor(fx + r), y_max = (int)floor(fy + r);
+  const double scale = (1.0 / r) * 16.0;
+  for (int y = y_min; y <= y_max; ++y) {
+    if (y < 0 || y >= (int)p.height) continue;
+    const int iy = (int)fmin(floor(fabs(((double)y - fy) * scale)), 15.0);
+    for (int x = x_min; x <= x_max; ++x) {
+      if (x < 0 || x >= (int)p.width) continue;
+      const int ix = (int)fmin(floor(fabs(((double)x - fx) * scale)), 15.0);
+      const float w = p.filter_table[iy * 16 + ix];
+      float* out = p.film + 4 * ((size_t)y * p.width + x);
+      unsafeAtomicAdd(out + 0, lr * w);
+      unsafeAtomicAdd(out + 1, lg * w);
+      unsafeAtomicAdd(out + 2, lb * w);
+      unsafeAtomicAdd(out + 3, w);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- start
 __global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam, uint32_t parity) {
   __shared__ uint32_t lens[kSegments + 1];
@@ -316,10 +344,17 @@ __global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam,
         } else {
           l4 = p.a.radiance[slot];
         }
-        float4 acc = p.a.accum[slot];
-        acc.x += l4.x; acc.y += l4.y; acc.z += l4.z; acc.w += 1.0f;
-        p.a.accum[slot] = acc;
-        sample = p.a.sample[slot] + p.n_samples;
+        const uint32_t finished = p.a.sample[slot];
+        if (p.filter_table) {
+          // the film position is the camera sample's (src/sampler.rs:76-83): pixel + draws 0, 1 of block 0
+          const Rng4 r = rng_block(p.seed, y * p.width + x, finished, 0);
+          splat_filtered(p, (double)x + (double)r.u[0], (double)y + (double)r.u[1], l4.x, l4.y, l4.z);
+        } else {
+          float4 acc = p.a.accum[slot];
+          acc.x += l4.x; acc.y += l4.y; acc.z += l4.z; acc.w += 1.0f;
+          p.a.accum[slot] = acc;
+        }
+        sample = finished + p.n_samples;
       }
       if (sample < p.sample_end) {
         const Rng4 r = rng_block(p.seed, y * p.width + x, sample, 0);
@@ -336,9 +371,12 @@ __global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam,
 // ---------------------------------------------------------------- extend
 // Block size in which a traversal kernel's waves take jobs from the global cursor: large enough
 // that the cursor sees few atomics, small enough that every wave comes back several times.
+#ifndef RRT_MAX_GRAB
+#define RRT_MAX_GRAB 1024
+#endif
 RRT_DEV uint32_t grab_size(uint32_t longest, uint32_t waves) {
   const uint32_t g = (longest * kSegments / (4u * waves) + 63u) & ~63u;
-  return min(max(g, 64u), 1024u);
+  return min(max(g, 64u), (uint32_t)RRT_MAX_GRAB);
 }
 
 // Continuation rays of `parity` first (they take longest), camera rays behind them.
@@ -652,6 +690,29 @@ __global__ void __launch_bounds__(256) k_film(RenderParams p) {
   float4 f = *out;
   f.x += r; f.y += g; f.z += b; f.w += w;
   *out = f;
+}
+
+// Film::merge_bucket_pixels_to_image_buffer's tone map (src/film.rs:233-249, 360-394).
+RRT_DEV float gamma_correct_srgb(float v) {
+  if (v <= 0.0f) return 0.0f;
+  if (v < 0.0031308f) return v * 12.92f;
+  if (v < 1.0f) return powf(v, 1.0f / 2.4f) * 1.055f - 0.055f;
+  return 1.0f;
+}
+__global__ void __launch_bounds__(256) k_tonemap(const float4* __restrict__ film, uint32_t n_pixels, uint8_t* __restrict__ rgb8) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pixels) return;
+  const float4 f = film[i];
+  uint8_t r = 0, g = 0, b = 0;
+  if (!(f.w < 2.220446049250313e-16f)) {
+    const float x = f.x / f.w, y = f.y / f.w, z = f.z / f.w;  // radiance goes into the XYZ matrix as it is
+    r = (uint8_t)(gamma_correct_srgb(3.240479f * x - 1.537150f * y - 0.498535f * z) * 255.0f);
+    g = (uint8_t)(gamma_correct_srgb(-0.969256f * x + 1.875991f * y + 0.041556f * z) * 255.0f);
+    b = (uint8_t)(gamma_correct_srgb(0.055648f * x - 0.204043f * y + 1.057311f * z) * 255.0f);
+  }
+  rgb8[3 * (size_t)i + 0] = r;
+  rgb8[3 * (size_t)i + 1] = g;
+  rgb8[3 * (size_t)i + 2] = b;
 }
 
 // Folds the pass's running counters into the statistics (one wave, lane = segment).

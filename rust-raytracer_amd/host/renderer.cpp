@@ -55,8 +55,6 @@ void check(rrt_ctx* ctx, int rc, const char* what) {
 std::unique_ptr<RenderJob> render(const Scene& scene, const Settings& settings, uint64_t seed, const Camera& camera,
                                   Film* film, const std::vector<int>& devices, uint32_t samples_per_merge) {
   if (devices.empty()) throw std::runtime_error("render: no devices given");
-  if (film->filter_method() != FilterMethod::None)
-    throw std::runtime_error("render: only filter_method none is implemented on the device");
   auto job = std::make_unique<RenderJob>();
   RenderJob* j = job.get();
   const size_t n_dev = devices.size();
@@ -78,6 +76,10 @@ std::unique_ptr<RenderJob> render(const Scene& scene, const Settings& settings, 
                                   camera.focal_distance),
               "rrt_set_camera");
         check(ctx, rrt_film_alloc(ctx, film->width(), film->height()), "rrt_film_alloc");
+        const uint32_t method = film->filter_method() == FilterMethod::Gaussian   ? RRT_FILTER_GAUSSIAN
+                                : film->filter_method() == FilterMethod::Mitchell ? RRT_FILTER_MITCHELL
+                                                                                  : RRT_FILTER_NONE;
+        check(ctx, rrt_set_filter(ctx, method, film->filter_radius()), "rrt_set_filter");
 
         rrt_settings s{};
         s.width = film->width();

@@ -242,6 +242,58 @@ def test_image_cornell_live(rrt, oracle_binding, cornell, gpu_ctx):
     assert rel <= 0.01
 
 
+@pytest.mark.parametrize("method,radius", [(1, 1.8), (2, 2.0), (1, 0.7)])
+def test_reconstruction_filters(rrt, oracle_binding, mixed, gpu_ctx, method, radius):
+    """Gaussian / Mitchell splat on the device (src/film.rs:169-215) against the oracle's, with a crop
+    window so that samples reach outside it, few slots so that the window takes several passes, and
+    several samples per pixel.  The device adds with float atomics: same terms, different order."""
+    scene, rs, _ = mixed
+    w, h, spp = 80, 60, 3
+    cam = rrt.Camera.from_settings(rs, w, h)
+    s = rrt.make_settings(w, h, 4, rs.clamp, seed=8, crop=(5, 4, 70, 57))
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    gpu_ctx.set_option(rrt.OPT_MAX_SLOTS, 64 * 40)
+    gpu_ctx.set_filter(method, radius)
+    try:
+        gpu_ctx.render(s, 0, spp)
+        dev = gpu_ctx.film_download().astype(np.float64)
+    finally:
+        gpu_ctx.set_filter(rrt.FILTER_NONE)
+        gpu_ctx.set_option(rrt.OPT_MAX_SLOTS, 32 << 20)
+    orc = oracle_binding.Oracle(scene.desc())
+    orc.set_camera(cam)
+    orc.set_filter(method, radius)
+    ref, _ = orc.render(s, 0, spp, threads=8)
+    # weights do not depend on the paths: they must agree to float rounding everywhere
+    np.testing.assert_allclose(dev[..., 3], ref[..., 3], rtol=2e-6, atol=1e-6)
+    outside = np.ones((h, w), bool)
+    outside[4:57, 5:70] = False
+    assert (ref[..., 3][outside] != 0).any()
+    rel = np.abs(dev[..., :3] - ref[..., :3]).sum() / np.abs(ref[..., :3]).sum()
+    print("filter %d radius %.1f: film rel diff %.3g" % (method, radius, rel))
+    assert rel <= 2e-3
+    # and the plain film still comes out afterwards
+    gpu_ctx.film_clear()
+    gpu_ctx.render(s, 0, 1)
+    plain = gpu_ctx.film_download()
+    assert set(np.unique(plain[..., 3])) == {0.0, 1.0}
+
+
+def test_device_tonemap(rrt, cornell, gpu_ctx):
+    """rrt_film_tonemap (src/film.rs:233-249) against the host tone map of the same film: f32 against
+    f64 may differ by one code value where the product lands on an integer."""
+    scene, rs = cornell
+    dev, cam, s = _device_film(rrt, gpu_ctx, scene, rs, 64, 64, 8, 4, 1, crop=(0, 0, 64, 60))
+    img = gpu_ctx.film_tonemap()
+    ref = rrt.tonemap(gpu_ctx.film_download())
+    assert img.shape == (64, 64, 3) and img.dtype == np.uint8
+    d = np.abs(img.astype(int) - ref.astype(int))
+    assert d.max() <= 1 and (d != 0).mean() < 0.01
+    assert (img[60:] == 0).all() and img[:60].max() > 50  # unrendered rows have no weight: black
+
+
 def test_crop_and_sample_ranges(rrt, cornell, gpu_ctx):
     """Sample ranges compose: [0,3) + [3,8) == [0,8); a crop only touches its window; batching
     (samples in flight, tile ranges) does not change the result."""

@@ -84,3 +84,53 @@ def test_clamp_bounds_the_running_sum(rrt, oracle_binding, mixed):
     d1a, _ = orc.render(rrt.make_settings(40, 30, 1, 0.25, seed=1), 0, 1, threads=4)
     d1b, _ = orc.render(rrt.make_settings(40, 30, 1, 1e9, seed=1), 0, 1, threads=4)
     assert (d1a[..., :3] <= d1b[..., :3] + 1e-12).all()
+
+
+def _filter_table(method, radius):
+    """Film::new's 16 x 16 table (src/film.rs:87-112, 326-358), restated in numpy."""
+    c = (np.arange(16) + 0.5) * radius / 16
+    if method == 1:  # Gaussian, alpha 1.5
+        e = np.exp(-1.5 * radius * radius)
+        g = np.maximum(np.exp(-1.5 * c * c) - e, 0.0)
+        return g[:, None] * g[None, :]
+    x = np.abs(2.0 * c / radius)
+    b = cc = 0.33
+    m = np.where(x > 1.0,
+                 ((-b - 6 * cc) * x ** 3 + (6 * b + 30 * cc) * x ** 2 + (-12 * b - 48 * cc) * x + (8 * b + 24 * cc)) / 6,
+                 ((12 - 9 * b - 6 * cc) * x ** 3 + (-18 + 12 * b + 6 * cc) * x ** 2 + (6 - 2 * b)) / 6)
+    return m[:, None] * m[None, :]
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_oracle_filter_splat(rrt, oracle_binding, cornell, method):
+    """Film::write_bucket_pixels with a filter (src/film.rs:169-215): the film is the splat of the
+    per-sample radiances, whatever the bucket size, and samples near the crop edge reach outside it."""
+    scene, rs = cornell
+    w, h, radius = 36, 28, 1.8
+    orc = oracle_binding.Oracle(scene.desc())
+    orc.set_camera(rrt.Camera.from_settings(rs, w, h))
+    s = rrt.make_settings(w, h, 3, rs.clamp, seed=6, crop=(4, 3, 30, 25))
+    plain, _ = orc.render(s, 0, 1, threads=2)  # filter none, 1 spp: the film holds each sample's radiance
+    orc.set_filter(method, radius)
+    film, _ = orc.render(s, 0, 1, threads=3, bucket=(8, 8))
+    film2, _ = orc.render(s, 0, 1, threads=1, bucket=(128, 128))
+    np.testing.assert_allclose(film, film2, rtol=1e-12, atol=1e-15)
+    table = _filter_table(method, radius)
+    L = oracle_binding.lib()
+    expect = np.zeros_like(film)
+    for y in range(3, 25):
+        for x in range(4, 30):
+            fx, fy = x + L.orc_rng(6, y * w + x, 0, 0, 0), y + L.orc_rng(6, y * w + x, 0, 0, 1)
+            for py in range(int(np.ceil(fy - radius)), int(np.floor(fy + radius)) + 1):
+                for px in range(int(np.ceil(fx - radius)), int(np.floor(fx + radius)) + 1):
+                    if 0 <= px < w and 0 <= py < h:
+                        ix = min(int(abs((px - fx) / radius * 16)), 15)
+                        iy = min(int(abs((py - fy) / radius * 16)), 15)
+                        wgt = table[iy, ix]
+                        expect[py, px, :3] += plain[y, x, :3] * wgt
+                        expect[py, px, 3] += wgt
+    np.testing.assert_allclose(film, expect, rtol=1e-9, atol=1e-12)
+    assert film[2, 10, 3] != 0.0 and film[0, 0, 3] == 0.0  # one row outside the crop is reached, the corner is not
+    orc.set_filter(0)
+    again, _ = orc.render(s, 0, 1, threads=2)
+    np.testing.assert_array_equal(again, plain)
