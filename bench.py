@@ -43,6 +43,7 @@ def _load(name, rel):
 rr = _load("rust_raytracer_amd", "rust-raytracer_amd/__init__.py")
 standin = _load("rust_raytracer_amd.standin", "rust-raytracer_amd/standin.py")
 rrdist = _load("rust_raytracer_amd.distributed", "rust-raytracer_amd/distributed.py")
+stress = _load("rust_raytracer_amd.stress", "rust-raytracer_amd/stress.py")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # algorithmic bytes per ray: 112 B per BVH node visited (four child boxes of six f32 + four links), 36 B per
@@ -109,6 +110,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--batch-samples", type=int, default=0)
     ap.add_argument("--no-calibrate", action="store_true")
+    ap.add_argument("--workload", choices=["buddha", "stress"], default="buddha",
+                    help="buddha: the headline configuration; stress: cow/lamp/teapot trios on a grid (depth 16)")
+    ap.add_argument("--trios", type=int, default=3200, help="stress workload: number of trios (15,632 triangles each)")
     args = ap.parse_args()
 
     import torch
@@ -130,9 +134,25 @@ def main():
     torch.cuda.set_device(device)
 
     W, H, SPP = args.width, args.height, args.spp
-    scene, rs, camera, mesh = load_buddha(W, H)
+    if args.workload == "stress":
+        t_gen = time.perf_counter()
+        scene, cam_args, depth_limit, clamp = stress.stress_scene(rr, args.trios)
+        camera = rr.Camera(image_width=W, image_height=H, **cam_args)
+        mesh = "%d generated trios" % args.trios
+        workload = "stress: %d cow/lamp/teapot trios on a grid, %dx%d, %d spp per GPU, depth %d, clamp %g, matte, distant + area light" % (
+            args.trios, W, H, SPP, depth_limit, clamp)
+        rs = None
+        if rank == 0:
+            print("stress scene generated in %.1f s" % (time.perf_counter() - t_gen), file=sys.stderr, flush=True)
+    else:
+        scene, rs, camera, mesh = load_buddha(W, H)
+        depth_limit, clamp = rs.depth_limit, rs.clamp
+        workload = ("scene/buddha %dx%d, %d spp per GPU, depth %d, clamp %g, aperture %g, microfacet plastic, "
+                    "3 area + distant + environment lights with MIS" % (W, H, SPP, depth_limit, clamp, rs.aperture))
     ctx = rr.Context(local_rank)
+    t_up = time.perf_counter()
     ctx.upload_scene(scene)
+    upload_s = time.perf_counter() - t_up
     ctx.set_camera(camera)
     film = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
     ctx.film_bind(film.data_ptr(), W, H)
@@ -140,7 +160,7 @@ def main():
     ctx.set_stream(ctypes.c_void_p(stream.cuda_stream))
     if args.batch_samples:
         ctx.set_option(rr.OPT_BATCH_SAMPLES, args.batch_samples)
-    settings = rr.make_settings(W, H, rs.depth_limit, rs.clamp, seed=0)
+    settings = rr.make_settings(W, H, depth_limit, clamp, seed=0)
     s_begin, s_end = rrdist.weak_sample_range(rank, SPP)
 
     def step():
@@ -219,10 +239,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "scene/buddha %dx%d, %d spp per GPU, depth %d, clamp %g, aperture %g, "
-                                   "microfacet plastic, 3 area + distant + environment lights with MIS" %
-                                   (W, H, SPP, rs.depth_limit, rs.clamp, rs.aperture),
-                       "mesh": mesh, "triangles": int(scene.desc().n_tris), "sharding": "sample index ranges per GPU"},
+            "config": {"workload": workload, "mesh": mesh, "triangles": int(scene.desc().n_tris),
+                       "bvh_nodes": int(st.bvh_nodes), "scene_bytes": int(st.bvh_bytes), "scene_upload_s": upload_s,
+                       "sharding": "sample index ranges per GPU"},
             "mrays_per_s": rays_rank * world / elapsed * 1e-6,
             "rays_per_path": rays_rank / float(st.paths) if st.paths else None,
             "bounces_per_path": st.path_bounces / float(st.paths) if st.paths else None,
@@ -231,7 +250,7 @@ def main():
                                    "film": st.ms_film / args.steps},
             "roofline": roofline,
         }
-        if world == 1 and (args.cpu_paths > 0 or args.cpu_seconds > 0):
+        if world == 1 and rs is not None and (args.cpu_paths > 0 or args.cpu_seconds > 0):
             out["cpu_baseline"] = cpu_baseline(scene, rs, args.cpu_threads, args.cpu_paths, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         else:

@@ -95,3 +95,14 @@ def buddha_scene(rrt, n_theta=242, n_v=141):
     pos, nrm = standin.happy_buddha_standin(n_theta, n_v)
     scene = rrt.Scene.load_from_folder_with_mesh(folder, pos, nrm, material)
     return scene, rs
+
+
+def stress_scene(rrt, n_trios, grid):
+    """The many-object workload (cow + lamp + teapot copies on a grid) at a size the oracle handles."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rust_raytracer_amd.stress", os.path.join(root, "rust-raytracer_amd", "stress.py"))
+    stress = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stress)
+    return stress, stress.stress_scene(rrt, n_trios, grid=grid)

@@ -153,6 +153,36 @@ def test_per_path_radiance_buddha(rrt, oracle_binding, buddha, gpu_ctx, depth):
     assert rel <= 1e-3
 
 
+def test_stress_scene(rrt, oracle_binding, gpu_ctx):
+    """24 cow / lamp / teapot trios (375 k triangles, generated normals, many separate objects),
+    depth limit 16: first hits, and per-path radiance with the distant and the area light."""
+    _, (scene, cam_args, depth, clamp) = scenes_util.stress_scene(rrt, 24, grid=(4, 3, 2))
+    assert scene.desc().n_tris == 24 * 15632 + 2
+    w, h = 128, 72
+    cam = rrt.Camera(image_width=w, image_height=h, **cam_args)
+    orc = oracle_binding.Oracle(scene.desc())
+    orc.set_camera(cam)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cam)
+    rng = np.random.default_rng(3)
+    px = rng.uniform(0, [w, h], size=(3000, 2))
+    primary = np.array([np.concatenate(cam.generate_ray(x, y)) for x, y in px])
+    sec = scenes_util.bounce_rays(orc, primary, rng)
+    rays = np.concatenate([primary, sec]).astype(np.float32).astype(np.float64)
+    ref_prim, ref_t, margin = orc.intersect(rays, with_margin=True)
+    _check_first_hit(gpu_ctx, rays, ref_prim, ref_t, margin)
+    s = rrt.make_settings(w, h, depth, clamp, seed=4)
+    gpu_ctx.film_alloc(w, h)
+    gpu_ctx.render(s, 0, 1)
+    dev = gpu_ctx.film_download().astype(np.float64)
+    ref, st = orc.render(s, 0, 1, threads=8)
+    close = _path_agreement(dev, ref)
+    print("stress scene: %.4f of paths agree; %.2f surface hits per path; mean ref %.5f dev %.5f" % (
+        close.mean(), st.path_bounces / st.paths, ref[..., :3].mean(), dev[..., :3].mean()))
+    assert st.path_bounces / st.paths > 0.5
+    assert close.mean() >= 0.998
+
+
 def _device_film(rrt, ctx, scene, rs, w, h, spp, depth, seed, crop=None):
     cam = rrt.Camera.from_settings(rs, w, h)
     s = rrt.make_settings(w, h, depth, rs.clamp, seed=seed, crop=crop)
