@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--cpu-paths", type=int, default=0, help="CPU baseline: camera paths when --cpu-seconds is 0 (both 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--batch-samples", type=int, default=0)
+    ap.add_argument("--max-slots", type=int, default=0, help="paths in flight (0 = library default, 32 Mi)")
     ap.add_argument("--no-calibrate", action="store_true")
     ap.add_argument("--workload", choices=["buddha", "stress"], default="buddha",
                     help="buddha: the headline configuration; stress: cow/lamp/teapot trios on a grid (depth 16)")
@@ -158,6 +159,8 @@ def main():
     ctx.film_bind(film.data_ptr(), W, H)
     stream = torch.cuda.current_stream(device)
     ctx.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    if args.max_slots:
+        ctx.set_option(rr.OPT_MAX_SLOTS, args.max_slots)
     if args.batch_samples:
         ctx.set_option(rr.OPT_BATCH_SAMPLES, args.batch_samples)
     settings = rr.make_settings(W, H, depth_limit, clamp, seed=0)

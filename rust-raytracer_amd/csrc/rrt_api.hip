@@ -23,8 +23,10 @@ namespace {
 
 thread_local std::string g_create_error;
 
-constexpr uint32_t kDefaultMaxSlots = 32u << 20;  // paths kept in flight per batch
+constexpr uint32_t kSlotLimit = 1u << 30;          // slot numbers share a word with two flag bits
+constexpr double kAutoMemoryShare = 0.6;           // automatic pool size: this share of the free device memory
 constexpr int kBlock = 256;
+constexpr uint32_t kMaxSlotsPerPixel = 1024;
 constexpr uint32_t kQueueGridBlocks = 8192;  // 32 blocks per CU for the kernels that walk a queue chunk by chunk
 constexpr uint32_t kTraceGridBlocks = 2048;  // 8 blocks = 32 waves per CU: at least what a CU can hold of the traversal kernels
 
@@ -82,7 +84,7 @@ struct rrt_ctx {
   bool timing = false;
   bool count_traversal = false;
   uint32_t batch_samples = 0;
-  uint32_t max_slots = kDefaultMaxSlots;
+  uint32_t max_slots = 0;  // 0: sized from the free device memory
 
   // timing
   std::vector<EventPair> events;
@@ -149,6 +151,15 @@ int state_alloc(rrt_ctx* ctx, T** out, size_t count) {
   int rc = dev_alloc(ctx, out, count);
   if (rc == RRT_OK) ctx->state_allocs.push_back(*out);
   return rc;
+}
+
+// Device memory ensure_state takes for n_slots slots (0 for none).
+uint64_t state_bytes(uint32_t n_slots, bool with_mis) {
+  if (n_slots == 0) return 0;
+  const uint64_t n = n_slots;
+  const uint64_t seg_cap = 2 * ((n + kSegments - 1) / kSegments) + n / 2048 + 4096;
+  const uint64_t ray_seg_cap = (n + kSegments - 1) / kSegments + 1024;
+  return n * (16ull * (with_mis ? 12 : 9) + 4) + 4ull * seg_cap * kSegments * 4 + 3ull * ray_seg_cap * kSegments * 32;
 }
 
 // Path state for n_slots paths and `depth` bounces; grows only.
@@ -354,7 +365,12 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
   }
   if ((rc = record_begin(ctx, 4)) != RRT_OK) return rc;
   // with a reconstruction filter the samples went into the film as their paths ended
-  if (!p.filter_table) hipLaunchKernelGGL(k_film, dim3(grid_for(p.n_tiles * 64)), dim3(kBlock), 0, ctx->stream, p);
+  if (!p.filter_table) {
+    uint32_t group = 1;  // lanes per pixel: the largest power of two that is at most min(K, 64)
+    while (group * 2 <= std::min(p.n_samples, 64u)) group *= 2;
+    const uint64_t threads = (uint64_t)p.n_tiles * 64 * group;
+    hipLaunchKernelGGL(k_film, dim3((uint32_t)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, p, group);
+  }
   hipLaunchKernelGGL(k_pass_stats, dim3(1), dim3(64), 0, ctx->stream, p);
   if ((rc = record_end(ctx)) != RRT_OK) return rc;
   HIP_TRY(ctx, hipGetLastError());
@@ -740,13 +756,24 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
 
   const uint32_t tiles_x = (win_w + 7) / 8, tiles_y = (win_h + 7) / 8;
   const uint64_t total_tiles = (uint64_t)tiles_x * tiles_y;
-  // batch shape: as many samples per pixel as fit (all of a pixel's samples sit in
-  // consecutive slots), and if one sample of the whole window does not fit, tile ranges
-  const uint64_t max_slots = ctx->max_slots;
-  uint32_t k = ctx->batch_samples ? ctx->batch_samples : (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, max_slots / (total_tiles * 64)));
+  // Pool shape: as many slots per pixel as fit, up to one per sample (all of a pixel's slots are
+  // consecutive), and if one slot per pixel of the whole window does not fit, tile ranges.
+  // The pool is as large as memory allows: a pass has a fixed cost -- the dozen last iterations
+  // with few paths left, each waiting for its longest rays -- and wide launches keep the rays of
+  // a wave together (one pixel, one bounce).  Measured at 1080p, 256 spp: 1.6 G samples/s with 16
+  // slots per pixel, 2.4 G with 64, 3.2 G with 256.
+  const bool need_mis = ctx->h_scene.has_env != 0;
+  uint64_t max_slots = ctx->max_slots;
+  if (max_slots == 0) {
+    size_t free_bytes = 0, total_bytes = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_bytes, &total_bytes));
+    const double have = (double)free_bytes + (double)state_bytes(ctx->state_slots, ctx->state_has_mis);
+    max_slots = (uint64_t)(have * kAutoMemoryShare / (double)state_bytes(1u << 20, need_mis) * (double)(1u << 20));
+    max_slots = std::min<uint64_t>(std::max<uint64_t>(max_slots, 1u << 16), kSlotLimit);
+  }
+  uint32_t k = ctx->batch_samples ? ctx->batch_samples : (uint32_t)std::min<uint64_t>(kMaxSlotsPerPixel, std::max<uint64_t>(1, max_slots / (total_tiles * 64)));
   k = std::min(k, n_samples);
   const uint32_t tiles_per_batch = (uint32_t)std::min<uint64_t>(total_tiles, std::max<uint64_t>(1, max_slots / (64ull * k)));
-  const bool need_mis = ctx->h_scene.has_env != 0;
   rc = ensure_state(ctx, tiles_per_batch * 64 * k, s->depth_limit, need_mis);
   if (rc != RRT_OK) return rc;
 
@@ -866,7 +893,7 @@ int rrt_set_option(rrt_ctx* ctx, int option, int64_t value) {
       ctx->batch_samples = (uint32_t)value;
       return RRT_OK;
     case RRT_OPT_MAX_SLOTS:
-      if (value < 64 || value > (int64_t)(1u << 30)) return fail(ctx, RRT_E_INVALID, "max slots out of range");
+      if (value != 0 && (value < 64 || value > (int64_t)kSlotLimit)) return fail(ctx, RRT_E_INVALID, "max slots out of range");
       ctx->max_slots = (uint32_t)value;
       return RRT_OK;
     case RRT_OPT_COUNT_TRAVERSAL: ctx->count_traversal = value != 0; return RRT_OK;

@@ -276,7 +276,6 @@ __global__ void __launch_bounds__(256) k_init(RenderParams p) {
   if (slot < p.n_slots) {
     uint32_t x, y, k;
     live = slot_pixel(p, slot, &x, &y, &k);
-    p.a.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   queue_push(p, p.a.q_start[0], row_start(0), blockIdx.x, live, slot | kFresh);
 }
@@ -350,7 +349,9 @@ __global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam,
           const Rng4 r = rng_block(p.seed, y * p.width + x, finished, 0);
           splat_filtered(p, (double)x + (double)r.u[0], (double)y + (double)r.u[1], l4.x, l4.y, l4.z);
         } else {
-          float4 acc = p.a.accum[slot];
+          // the slot's first finished path initialises its sum, so the array needs no clearing pass
+          float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (finished != p.sample_begin + k) acc = p.a.accum[slot];
           acc.x += l4.x; acc.y += l4.y; acc.z += l4.z; acc.w += 1.0f;
           p.a.accum[slot] = acc;
         }
@@ -673,23 +674,37 @@ __global__ void RRT_TRACE_BOUNDS k_connect(RenderParams p) {
 }
 
 // ---------------------------------------------------------------- film
-// One thread per pixel of the pass: adds the sums of its K slots to the film.  A pixel belongs to
-// one thread of one pass at a time, so no atomics are needed and the sum is reproducible.
-__global__ void __launch_bounds__(256) k_film(RenderParams p) {
-  const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= p.n_tiles * 64) return;
-  uint32_t x, y, k;
-  if (!slot_pixel(p, pix * p.n_samples, &x, &y, &k)) return;
-  float r = 0.0f, g = 0.0f, b = 0.0f, w = 0.0f;
-  const float4* acc = p.a.accum + (size_t)pix * p.n_samples;
-  for (uint32_t s = 0; s < p.n_samples; ++s) {
-    const float4 v = acc[s];
-    r += v.x; g += v.y; b += v.z; w += v.w;
+// Adds the sums of a pixel's K slots to the film.  A group of G lanes (a power of two, at most a
+// wave) shares a pixel: lane g adds slots g, g + G, ... in that order, then the lanes' sums are
+// combined pairwise -- consecutive lanes read consecutive slots, and the order of the additions is
+// fixed, so the result is reproducible.  A pixel belongs to one group of one pass at a time: no
+// atomics.  Every live slot has banked at least one path (its first sample), so `accum` holds no
+// stale values where it is read.
+__global__ void __launch_bounds__(256) k_film(RenderParams p, uint32_t group) {
+  const uint32_t thread = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t pix = thread / group, g = thread % group;
+  uint32_t x = 0, y = 0, k;
+  const bool live = pix < p.n_tiles * 64 && slot_pixel(p, pix * p.n_samples, &x, &y, &k);
+  float r = 0.0f, gr = 0.0f, b = 0.0f, w = 0.0f;
+  if (live) {
+    const float4* acc = p.a.accum + (size_t)pix * p.n_samples;
+    for (uint32_t s = g; s < p.n_samples; s += group) {
+      const float4 v = acc[s];
+      r += v.x; gr += v.y; b += v.z; w += v.w;
+    }
   }
-  float4* out = reinterpret_cast<float4*>(p.film) + ((size_t)y * p.width + x);
-  float4 f = *out;
-  f.x += r; f.y += g; f.z += b; f.w += w;
-  *out = f;
+  for (uint32_t d = group >> 1; d > 0; d >>= 1) {
+    r += __shfl_xor(r, d);
+    gr += __shfl_xor(gr, d);
+    b += __shfl_xor(b, d);
+    w += __shfl_xor(w, d);
+  }
+  if (live && g == 0) {
+    float4* out = reinterpret_cast<float4*>(p.film) + ((size_t)y * p.width + x);
+    float4 f = *out;
+    f.x += r; f.y += gr; f.z += b; f.w += w;
+    *out = f;
+  }
 }
 
 // Film::merge_bucket_pixels_to_image_buffer's tone map (src/film.rs:233-249, 360-394).
