@@ -323,10 +323,6 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
   // traversal kernels: enough blocks to fill every CU; their waves take jobs from a cursor
   const uint32_t trace_grid = std::min(grid_all + 1, kTraceGridBlocks);
   int rc;
-  if ((rc = record_begin(ctx, 0)) != RRT_OK) return rc;
-  hipLaunchKernelGGL(k_init, dim3(grid_all), dim3(kBlock), 0, ctx->stream, p);
-  if ((rc = record_end(ctx)) != RRT_OK) return rc;
-
   const uint32_t per_slot = (p.sample_end - p.sample_begin + p.n_samples - 1) / p.n_samples;
   // a slot needs at least one iteration per sample plus one to retire, at most depth_limit per sample
   const uint64_t max_iterations = (uint64_t)per_slot * p.depth_limit + 2;
@@ -337,13 +333,22 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
       const uint32_t parity = (uint32_t)(it & 1), next = parity ^ 1u;
       // camera, shade, shadow and the two queues of the other parity start this iteration empty
       HIP_TRY(ctx, hipMemsetAsync(p.a.counters + row_words * 2 * next, 0, row_bytes * kRowsPerIteration, ctx->stream));
-      if ((rc = record_begin(ctx, 0)) != RRT_OK) return rc;
-      hipLaunchKernelGGL(k_start, dim3(grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, parity);
-      if ((rc = record_end(ctx)) != RRT_OK) return rc;
-      if ((rc = record_begin(ctx, 1)) != RRT_OK) return rc;
-      if (ctx->count_traversal) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, parity);
-      else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, parity);
-      if ((rc = record_end(ctx)) != RRT_OK) return rc;
+      if (it == 0) {
+        // the first camera ray of every slot: generated and traced by one kernel
+        const uint32_t single = per_slot == 1 ? 1u : 0u;
+        if ((rc = record_begin(ctx, 1)) != RRT_OK) return rc;
+        if (ctx->count_traversal) hipLaunchKernelGGL(k_primary<true>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, single);
+        else hipLaunchKernelGGL(k_primary<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, single);
+        if ((rc = record_end(ctx)) != RRT_OK) return rc;
+      } else {
+        if ((rc = record_begin(ctx, 0)) != RRT_OK) return rc;
+        hipLaunchKernelGGL(k_start, dim3(grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, parity);
+        if ((rc = record_end(ctx)) != RRT_OK) return rc;
+        if ((rc = record_begin(ctx, 1)) != RRT_OK) return rc;
+        if (ctx->count_traversal) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, parity);
+        else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, parity);
+        if ((rc = record_end(ctx)) != RRT_OK) return rc;
+      }
       if ((rc = record_begin(ctx, 2)) != RRT_OK) return rc;
       hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, ctx->stream, p, parity);
       if ((rc = record_end(ctx)) != RRT_OK) return rc;

@@ -1,10 +1,11 @@
 // The streaming wavefront path tracer: the stages of trace() (src/tracer.rs:24-139) as kernels
 // that run once per iteration over queues of path slots.
 //
+//   primary  iteration 0: every slot's first camera ray, generated (src/sampler.rs:76-83,
+//            src/camera.rs:103-125) and traced by one kernel
 //   start    slots whose path has ended: a ray that escaped picks up the environment if it was a
 //            camera ray or followed a specular bounce (src/tracer.rs:44-63); the finished radiance
 //            is banked; the slot takes its next sample and generates the camera ray
-//            (src/sampler.rs:76-83, src/camera.rs:103-125)
 //   extend   check_intersect_scene (src/renderer.rs:213-249) for camera and continuation rays.
 //            Nothing else lives in this kernel: its register count decides how many rays a CU
 //            keeps in flight.
@@ -55,8 +56,7 @@ constexpr uint32_t kHasLightRay = 1u, kHasMisRay = 2u, kClamp = 4u;
 
 constexpr int kSegments = 64;        // queue segments = lanes of a wave (one lane scans one counter)
 constexpr int kCounterStride = 32;   // words between counters: each sits in a 128-byte line of its own
-// Flags of a start-queue entry (slot numbers stay below 2^30).
-constexpr uint32_t kFresh = 0x80000000u;    // the slot has no finished path to bank yet
+// Flag of a start-queue entry (slot numbers stay below 2^30).
 constexpr uint32_t kEscaped = 0x40000000u;  // the path ended because its ray left the scene
 constexpr uint32_t kSlotMask = 0x3fffffffu;
 
@@ -268,18 +268,6 @@ RRT_DEV const float4* ray_queue_block(const RenderParams& p, const float4* __res
   return queue + ((size_t)seg * p.a.ray_seg_cap + first) * 2;
 }
 
-// ---------------------------------------------------------------- init
-// Every slot of a pixel inside the window enters the first start queue.
-__global__ void __launch_bounds__(256) k_init(RenderParams p) {
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  bool live = false;
-  if (slot < p.n_slots) {
-    uint32_t x, y, k;
-    live = slot_pixel(p, slot, &x, &y, &k);
-  }
-  queue_push(p, p.a.q_start[0], row_start(0), blockIdx.x, live, slot | kFresh);
-}
-
 // Film::write_bucket_pixels with a reconstruction filter (src/film.rs:169-215): the sample at film
 // position (fx, fy) adds weight * L to every pixel within the radius.  Pixels are shared between
 // slots here, so the sums are atomic (their order, and with it the last bits of the film, varies
@@ -320,43 +308,39 @@ __global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam,
     if (i < n) {
       const uint32_t entry = entries[i];
       slot = entry & kSlotMask;
-      uint32_t x, y, k, sample;
+      uint32_t x, y, k;
       slot_pixel(p, slot, &x, &y, &k);
-      if (entry & kFresh) {
-        sample = p.sample_begin + k;
-      } else {
-        float4 l4;
-        if (entry & kEscaped) {
-          const float4 d = p.a.ray_d[slot];
-          const uint32_t state = __float_as_uint(d.w);
-          if (state == 0u) {
-            // a camera ray that escapes sees the lights' environment term (src/tracer.rs:50-53)
-            l4 = f4(escape_radiance(p.scene, p.env, mk(d)), 0.0f);
-          } else {
-            l4 = p.a.radiance[slot];
-            if (state & 1u) {  // later rays only after a specular bounce (src/tracer.rs:44-63)
-              const V3 le = escape_radiance(p.scene, p.env, mk(d));
-              const float4 b = p.a.beta[slot];
-              l4.x += b.x * le.x; l4.y += b.y * le.y; l4.z += b.z * le.z;
-            }
-          }
+      float4 l4;
+      if (entry & kEscaped) {
+        const float4 d = p.a.ray_d[slot];
+        const uint32_t state = __float_as_uint(d.w);
+        if (state == 0u) {
+          // a camera ray that escapes sees the lights' environment term (src/tracer.rs:50-53)
+          l4 = f4(escape_radiance(p.scene, p.env, mk(d)), 0.0f);
         } else {
           l4 = p.a.radiance[slot];
+          if (state & 1u) {  // later rays only after a specular bounce (src/tracer.rs:44-63)
+            const V3 le = escape_radiance(p.scene, p.env, mk(d));
+            const float4 b = p.a.beta[slot];
+            l4.x += b.x * le.x; l4.y += b.y * le.y; l4.z += b.z * le.z;
+          }
         }
-        const uint32_t finished = p.a.sample[slot];
-        if (p.filter_table) {
-          // the film position is the camera sample's (src/sampler.rs:76-83): pixel + draws 0, 1 of block 0
-          const Rng4 r = rng_block(p.seed, y * p.width + x, finished, 0);
-          splat_filtered(p, (double)x + (double)r.u[0], (double)y + (double)r.u[1], l4.x, l4.y, l4.z);
-        } else {
-          // the slot's first finished path initialises its sum, so the array needs no clearing pass
-          float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          if (finished != p.sample_begin + k) acc = p.a.accum[slot];
-          acc.x += l4.x; acc.y += l4.y; acc.z += l4.z; acc.w += 1.0f;
-          p.a.accum[slot] = acc;
-        }
-        sample = finished + p.n_samples;
+      } else {
+        l4 = p.a.radiance[slot];
       }
+      const uint32_t finished = p.a.sample[slot];
+      if (p.filter_table) {
+        // the film position is the camera sample's (src/sampler.rs:76-83): pixel + draws 0, 1 of block 0
+        const Rng4 r = rng_block(p.seed, y * p.width + x, finished, 0);
+        splat_filtered(p, (double)x + (double)r.u[0], (double)y + (double)r.u[1], l4.x, l4.y, l4.z);
+      } else {
+        // the slot's first finished path initialises its sum, so the array needs no clearing pass
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (finished != p.sample_begin + k) acc = p.a.accum[slot];
+        acc.x += l4.x; acc.y += l4.y; acc.z += l4.z; acc.w += 1.0f;
+        p.a.accum[slot] = acc;
+      }
+      const uint32_t sample = finished + p.n_samples;
       if (sample < p.sample_end) {
         const Rng4 r = rng_block(p.seed, y * p.width + x, sample, 0);
         camera_ray(cam, x, y, r, &org, &dir);
@@ -460,6 +444,98 @@ __global__ void RRT_TRACE_BOUNDS k_extend(RenderParams p, uint32_t parity) {
   ExtendJob<COUNT> job = {p, sc, lens_c, lens_s, blocks_c, grab, parity, nullptr, 0, 0, false, 0, false};
   trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
                              blocks_c + queue_blocks(longest_s, grab), job, &ctr, rrt_trace_stack);
+  flush_counters<COUNT>(p.stats, ctr);
+}
+
+// ---------------------------------------------------------------- primary
+// Iteration 0 in one kernel: every slot generates its first camera ray (as k_start would) and
+// traces it at once (as k_extend would), without the ray going through a queue in memory.  When
+// every slot has a single sample (`single`) a camera ray that escapes ends its slot right here:
+// three quarters of the bench scene's paths then cost one 16-byte store.
+template <bool COUNT>
+struct PrimaryJob {
+  const RenderParams& p;
+  const CameraParams& cam;
+  const SceneTables* sc;  // LDS copy of the shapes
+  uint32_t grab;
+  bool single;            // one sample per slot and no reconstruction filter
+  uint32_t base, slot;
+  int kind;               // 0 nothing to hand in, 1 to shade, 2 to start (escaped)
+  uint32_t out_slot;      // result of the retired job, until the flush
+  int out_kind;
+  bool out_started;
+
+  RRT_DEV uint32_t open_block(uint32_t j) {
+    base = j * grab;
+    return min(grab, p.n_slots - base);
+  }
+  RRT_DEV bool begin(uint32_t i, Ray* ray) {
+    slot = base + i;
+    kind = -1;  // not a path: a slot of a tile's padding
+    uint32_t x, y, k;
+    if (!slot_pixel(p, slot, &x, &y, &k)) return false;
+    kind = 0;
+    const uint32_t sample = p.sample_begin + k;
+    const Rng4 r = rng_block(p.seed, y * p.width + x, sample, 0);
+    camera_ray(cam, x, y, r, &ray->o, &ray->d);
+    ray->tmin = 0.0f;
+    ray->tmax = kTriTMax;
+    ray->skip = -1;
+    p.a.sample[slot] = sample;
+    return true;
+  }
+  RRT_DEV bool advance(bool found, const Hit& tri_hit, const RayPre& r, Ray*) {
+    Hit h = tri_hit;
+    if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
+    if (h.prim >= 0) {
+      p.a.ray_o[slot] = f4(r.o, 0.0f);
+      p.a.ray_d[slot] = f4(r.d, __uint_as_float(0u));
+      p.a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+      kind = 1;
+    } else if (single) {
+      // a camera ray that escapes sees the lights' environment term (src/tracer.rs:50-53): the
+      // slot's only path is complete, and its sum is that radiance
+      p.a.accum[slot] = f4(escape_radiance(p.scene, p.env, r.d), 1.0f);
+      kind = 0;
+    } else {
+      p.a.ray_d[slot] = f4(r.d, __uint_as_float(0u));
+      kind = 2;
+    }
+    return false;
+  }
+  RRT_DEV void retire() {
+    out_slot = slot;
+    out_kind = kind < 0 ? 0 : kind;
+    out_started = kind >= 0;
+  }
+  RRT_DEV void flush(bool done, uint32_t block) {
+    const bool to_shade = done && out_kind == 1, to_start = done && out_kind == 2;
+    const unsigned long long mask_h = __ballot(to_shade), mask_m = __ballot(to_start);
+    const int lane = threadIdx.x & 63;
+    const int leader_h = mask_h ? __ffsll((long long)mask_h) - 1 : 0, leader_m = mask_m ? __ffsll((long long)mask_m) - 1 : 0;
+    const uint32_t seg = block % kSegments;
+    uint32_t base_h = 0, base_m = 0;
+    if (mask_h && lane == leader_h) base_h = atomicAdd(counter_at(p.a.counters, kRowShade, seg), (uint32_t)__popcll(mask_h));
+    if (mask_m && lane == leader_m) base_m = atomicAdd(counter_at(p.a.counters, row_start(1), seg), (uint32_t)__popcll(mask_m));
+    base_h = __shfl(base_h, leader_h);
+    base_m = __shfl(base_m, leader_m);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (to_shade) p.a.q_shade[seg * p.a.seg_cap + base_h + __popcll(mask_h & below)] = out_slot;
+    if (to_start) p.a.q_start[1][seg * p.a.seg_cap + base_m + __popcll(mask_m & below)] = out_slot | kEscaped;
+    counter_add(p, kRowPaths, block, done && out_started);
+  }
+};
+
+template <bool COUNT>
+__global__ void RRT_TRACE_BOUNDS k_primary(RenderParams p, CameraParams cam, uint32_t single) {
+  RRT_DECLARE_TRACE_STACK();
+  RRT_DECLARE_SHAPES();
+  const SceneTables* sc = shapes_to_lds(p.scene, rrt_shape_words);
+  const uint32_t grab = grab_size((p.n_slots + kSegments - 1) / kSegments, gridDim.x * (kTraceBlock / 64));
+  TraceCounters ctr = {0, 0};
+  PrimaryJob<COUNT> job = {p, cam, sc, grab, single != 0 && p.filter_table == nullptr, 0, 0, 0, 0, 0, false};
+  trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
+                             (p.n_slots + grab - 1) / grab, job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, ctr);
 }
 
