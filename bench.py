@@ -9,8 +9,8 @@ the reference snapshot, so a generated stand-in of the same triangle count is us
 scenes/buddha/happy-buddha.obj exists.  Synthetic data, no files are read from the reference.
 
 One step = one pass of the hot path over the whole frame: rrt_render of 256 samples of every pixel
-(raygen, then extend / shade / connect per bounce, then film accumulation), scene and film resident
-in HBM before the clock starts.  With N GPUs (launched by torch.distributed.run, one rank per GPU)
+(primary, then start / extend / shade / connect per iteration, then film accumulation), scene and film
+resident in HBM before the clock starts.  With N GPUs (launched by torch.distributed.run, one rank per GPU)
 rank r renders sample indices [256 r, 256 (r+1)) and the per-GPU films are summed onto rank 0 with
 one RCCL reduce inside the timed region: weak scaling, value = all ranks' camera paths / max time.
 
@@ -176,16 +176,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # ---- calibration (untimed): nodes / triangles fetched per ray, for the roofline's algorithmic bytes
+    # ---- calibration (untimed): nodes / triangles fetched per ray of each traversal kernel, for the
+    # roofline's algorithmic bytes (a counting build of the same kernels; per-ray means do not depend on spp)
     per_ray = None
     if rank == 0 and not args.no_calibrate:
         ctx.set_option(rr.OPT_COUNT_TRAVERSAL, 1)
         ctx.reset_stats()
         film.zero_()
-        ctx.render(settings, s_begin, s_begin + 2)
+        ctx.render(settings, s_begin, s_begin + min(8, SPP))
         st = ctx.stats()
-        rays = st.rays_extend + st.rays_shadow
-        per_ray = (st.nodes_visited / rays, st.tris_tested / rays)
+        rays = (st.rays_primary, st.rays_extend - st.rays_primary, st.rays_shadow)
+        per_ray = [(st.nodes_by_kernel[k] / max(rays[k], 1), st.tris_by_kernel[k] / max(rays[k], 1)) for k in range(3)]
         ctx.set_option(rr.OPT_COUNT_TRAVERSAL, 0)
 
     for _ in range(args.warmup):
@@ -215,20 +216,29 @@ def main():
         assert abs(fsum[3] - float(W) * H * SPP * world) < 1e-3 * W * H * SPP * world, fsum
         assert all(x == x and x > 0 for x in fsum[:3]), fsum
         roofline = None
+        kernels = None
         if per_ray is not None and st.launches_extend:
-            bytes_per_ray = per_ray[0] * NODE_BYTES + per_ray[1] * TRI_BYTES + RAY_BYTES + HIT_BYTES
-            launch_bytes = st.rays_extend * bytes_per_ray / st.launches_extend
-            launch_s = st.ms_extend * 1e-3 / st.launches_extend
-            achieved = launch_bytes / launch_s * 1e-9
+            def entry(name, k, n_rays, launches, ms):
+                bytes_per_ray = per_ray[k][0] * NODE_BYTES + per_ray[k][1] * TRI_BYTES + RAY_BYTES + HIT_BYTES
+                gbs = n_rays * bytes_per_ray / (ms * 1e-3) * 1e-9 if ms > 0 else 0.0
+                return {"kernel": name, "rays_per_launch": n_rays / max(launches, 1), "bytes_per_ray": bytes_per_ray,
+                        "nodes_per_ray": per_ray[k][0], "tris_per_ray": per_ray[k][1], "launches": int(launches),
+                        "avg_launch_ms": ms / max(launches, 1), "algorithmic_gb_per_s": gbs}
+            kernels = [entry("k_primary", 0, st.rays_primary, st.launches_primary, st.ms_primary),
+                       entry("k_extend", 1, st.rays_extend - st.rays_primary, st.launches_extend, st.ms_extend),
+                       entry("k_connect", 2, st.rays_shadow, st.launches_extend + st.launches_primary, st.ms_connect)]
+            # the dominant kernel by time: k_extend (continuation rays)
+            e = kernels[1]
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic = json.load(f).get("hbm_bytes_per_launch")
-            roofline = {"kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                        "bytes_per_ray": bytes_per_ray, "nodes_per_ray": per_ray[0], "tris_per_ray": per_ray[1],
-                        "launches": int(st.launches_extend), "avg_launch_ms": st.ms_extend / st.launches_extend}
+            roofline = {"kernel": "k_extend", "bound": "hbm", "achieved": e["algorithmic_gb_per_s"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": e["algorithmic_gb_per_s"] / HBM_PEAK_GBS, "traffic": traffic,
+                        "bytes_per_ray": e["bytes_per_ray"], "nodes_per_ray": e["nodes_per_ray"],
+                        "tris_per_ray": e["tris_per_ray"], "launches": e["launches"], "avg_launch_ms": e["avg_launch_ms"],
+                        "rays_per_launch": e["rays_per_launch"]}
         out = {
             "metric": "camera-path samples/sec",
             "value": value,
@@ -248,10 +258,12 @@ def main():
             "mrays_per_s": rays_rank * world / elapsed * 1e-6,
             "rays_per_path": rays_rank / float(st.paths) if st.paths else None,
             "bounces_per_path": st.path_bounces / float(st.paths) if st.paths else None,
-            "kernel_ms_per_step": {"raygen": st.ms_raygen / args.steps, "extend": st.ms_extend / args.steps,
+            "kernel_ms_per_step": {"primary": st.ms_primary / args.steps, "start": st.ms_raygen / args.steps,
+                                   "extend": st.ms_extend / args.steps,
                                    "shade": st.ms_shade / args.steps, "connect": st.ms_connect / args.steps,
                                    "film": st.ms_film / args.steps},
             "roofline": roofline,
+            "traversal_kernels": kernels,
         }
         if world == 1 and rs is not None and (args.cpu_paths > 0 or args.cpu_seconds > 0):
             out["cpu_baseline"] = cpu_baseline(scene, rs, args.cpu_threads, args.cpu_paths, args.cpu_seconds)

@@ -145,12 +145,19 @@ typedef struct rrt_stats {
   uint64_t rays_extend;      /* closest-hit queries (src/renderer.rs:213) */
   uint64_t rays_shadow;      /* any-hit queries (src/renderer.rs:251) incl. MIS escape rays */
   uint64_t path_bounces;     /* surface interactions shaded */
-  double ms_raygen, ms_extend, ms_shade, ms_connect, ms_film; /* kernel time, valid when timing is on */
-  uint64_t launches_extend;  /* extend launches the times above cover */
+  double ms_raygen, ms_extend, ms_shade, ms_connect, ms_film; /* kernel time, valid when timing is on; raygen = start kernels,
+                                                                 extend = continuation-ray kernels only (see ms_primary) */
+  uint64_t launches_extend;  /* extend launches ms_extend covers */
   uint64_t nodes_visited;    /* BVH nodes fetched, counted only while RRT_OPT_COUNT_TRAVERSAL is on */
   uint64_t tris_tested;      /* triangle records fetched, counted likewise */
   uint64_t bvh_nodes;
   uint64_t bvh_bytes;        /* node + triangle bytes resident on the device */
+  /* the same counts per traversal kernel: [0] primary (first camera ray of every slot), [1] extend
+   * (continuation rays and later camera rays), [2] connect (visibility rays) */
+  uint64_t nodes_by_kernel[3], tris_by_kernel[3];
+  double ms_primary;         /* kernel time of the primary kernels */
+  uint64_t launches_primary;
+  uint64_t rays_primary;     /* closest-hit queries made by the primary kernels (part of rays_extend) */
 } rrt_stats;
 
 /* Number of visible HIP devices, or a negative code. */

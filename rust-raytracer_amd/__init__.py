@@ -71,7 +71,9 @@ class Stats(C.Structure):
                 ("path_bounces", C.c_uint64), ("ms_raygen", C.c_double), ("ms_extend", C.c_double),
                 ("ms_shade", C.c_double), ("ms_connect", C.c_double), ("ms_film", C.c_double),
                 ("launches_extend", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
-                ("bvh_nodes", C.c_uint64), ("bvh_bytes", C.c_uint64)]
+                ("bvh_nodes", C.c_uint64), ("bvh_bytes", C.c_uint64),
+                ("nodes_by_kernel", C.c_uint64 * 3), ("tris_by_kernel", C.c_uint64 * 3),
+                ("ms_primary", C.c_double), ("launches_primary", C.c_uint64), ("rays_primary", C.c_uint64)]
 
 
 class RenderSettingsFile(C.Structure):

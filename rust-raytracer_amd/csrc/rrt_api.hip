@@ -34,7 +34,7 @@ inline uint32_t grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 struct EventPair {
   hipEvent_t begin, end;
-  int stage;  // 0 raygen, 1 extend, 2 shade, 3 connect, 4 film
+  int stage;  // 0 start, 1 extend, 2 shade, 3 connect, 4 film, 5 primary
 };
 
 }  // namespace
@@ -89,8 +89,8 @@ struct rrt_ctx {
   // timing
   std::vector<EventPair> events;
   size_t events_used = 0;
-  double ms[5] = {0, 0, 0, 0, 0};
-  uint64_t launches_extend = 0;
+  double ms[6] = {0, 0, 0, 0, 0, 0};  // start, extend, shade, connect, film, primary
+  uint64_t launches_extend = 0, launches_primary = 0, rays_primary = 0;
 };
 
 namespace {
@@ -304,6 +304,7 @@ int collect_timing(rrt_ctx* ctx) {
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->events[i].begin, ctx->events[i].end));
     ctx->ms[ctx->events[i].stage] += ms;
     if (ctx->events[i].stage == 1) ctx->launches_extend++;
+    if (ctx->events[i].stage == 5) ctx->launches_primary++;
   }
   ctx->events_used = 0;
   return RRT_OK;
@@ -336,7 +337,7 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
       if (it == 0) {
         // the first camera ray of every slot: generated and traced by one kernel
         const uint32_t single = per_slot == 1 ? 1u : 0u;
-        if ((rc = record_begin(ctx, 1)) != RRT_OK) return rc;
+        if ((rc = record_begin(ctx, 5)) != RRT_OK) return rc;
         if (ctx->count_traversal) hipLaunchKernelGGL(k_primary<true>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, single);
         else hipLaunchKernelGGL(k_primary<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, single);
         if ((rc = record_end(ctx)) != RRT_OK) return rc;
@@ -813,6 +814,11 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
     p.n_samples = k;
     p.n_slots = p.n_tiles * 64 * k;
     if ((rc = launch_pass(ctx, p)) != RRT_OK) return rc;
+    // the primary kernel traced one ray for every slot of a pixel inside the window
+    for (uint64_t t = t0; t < t0 + p.n_tiles; ++t) {
+      const uint32_t tx = (uint32_t)(t % tiles_x), ty = (uint32_t)(t / tiles_x);
+      ctx->rays_primary += (uint64_t)std::min(8u, win_w - tx * 8) * std::min(8u, win_h - ty * 8) * k;
+    }
   }
   return RRT_OK;
 }
@@ -919,8 +925,15 @@ int rrt_get_stats(rrt_ctx* ctx, rrt_stats* out) {
   out->rays_extend = ds.rays_extend;
   out->rays_shadow = ds.rays_shadow;
   out->path_bounces = ds.path_bounces;
-  out->nodes_visited = ds.nodes_visited;
-  out->tris_tested = ds.tris_tested;
+  for (int k = 0; k < 3; ++k) {
+    out->nodes_by_kernel[k] = ds.nodes[k];
+    out->tris_by_kernel[k] = ds.tris[k];
+    out->nodes_visited += ds.nodes[k];
+    out->tris_tested += ds.tris[k];
+  }
+  out->ms_primary = ctx->ms[5];
+  out->launches_primary = ctx->launches_primary;
+  out->rays_primary = ctx->rays_primary;
   out->ms_raygen = ctx->ms[0];
   out->ms_extend = ctx->ms[1];
   out->ms_shade = ctx->ms[2];
@@ -934,8 +947,8 @@ int rrt_get_stats(rrt_ctx* ctx, rrt_stats* out) {
     unsigned long long dbg[32];
     if (hipMemcpyFromSymbol(dbg, HIP_SYMBOL(rrt_phase_dbg), sizeof(dbg)) == hipSuccess) {
       for (int k = 0; k < 32; k += 16)
-        std::fprintf(stderr, "phase clocks (%s): refill %llu (advance %llu begin %llu flush %llu) node %llu leaf %llu | node iters %llu leaf iters %llu | lanes stepping %llu at leaf %llu | refills %llu total %llu\n",
-                     k ? "any hit" : "closest hit", dbg[k + 0], dbg[k + 10], dbg[k + 11], dbg[k + 12], dbg[k + 1], dbg[k + 2], dbg[k + 3], dbg[k + 4], dbg[k + 5], dbg[k + 6], dbg[k + 7], dbg[k + 8]);
+        std::fprintf(stderr, "phase clocks (%s): refill %llu (advance %llu begin %llu flush %llu) node %llu leaf %llu | node iters %llu leaf iters %llu | lanes stepping %llu at leaf %llu | refills %llu total %llu | longest ray %llu node steps, %llu rays above 256, %llu above 1024\n",
+                     k ? "any hit" : "closest hit", dbg[k + 0], dbg[k + 10], dbg[k + 11], dbg[k + 12], dbg[k + 1], dbg[k + 2], dbg[k + 3], dbg[k + 4], dbg[k + 5], dbg[k + 6], dbg[k + 7], dbg[k + 8], dbg[k + 13], dbg[k + 14], dbg[k + 15]);
       std::memset(dbg, 0, sizeof(dbg));
       (void)hipMemcpyToSymbol(HIP_SYMBOL(rrt_phase_dbg), dbg, sizeof(dbg));
     }
@@ -951,7 +964,7 @@ int rrt_reset_stats(rrt_ctx* ctx) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)));
   for (double& m : ctx->ms) m = 0.0;
-  ctx->launches_extend = 0;
+  ctx->launches_extend = ctx->launches_primary = ctx->rays_primary = 0;
   return RRT_OK;
 }
 

@@ -48,7 +48,8 @@
 namespace rrt {
 
 struct DeviceStats {
-  unsigned long long paths, rays_extend, rays_shadow, path_bounces, nodes_visited, tris_tested;
+  unsigned long long paths, rays_extend, rays_shadow, path_bounces, rays_primary;
+  unsigned long long nodes[3], tris[3];  // per traversal kernel: primary, extend, connect
 };
 
 // Flags kept in the w lane of the shadow-contribution record.
@@ -224,10 +225,10 @@ RRT_DEV const SceneTables* shapes_to_lds(const SceneTables* __restrict__ scene, 
 }
 
 template <bool COUNT>
-RRT_DEV void flush_counters(DeviceStats* stats, const TraceCounters& ctr) {
+RRT_DEV void flush_counters(DeviceStats* stats, int kernel, const TraceCounters& ctr) {
   if (COUNT) {
-    atomicAdd(&stats->nodes_visited, (unsigned long long)ctr.nodes);
-    atomicAdd(&stats->tris_tested, (unsigned long long)ctr.tris);
+    atomicAdd(&stats->nodes[kernel], (unsigned long long)ctr.nodes);
+    atomicAdd(&stats->tris[kernel], (unsigned long long)ctr.tris);
   }
 }
 
@@ -444,7 +445,7 @@ __global__ void RRT_TRACE_BOUNDS k_extend(RenderParams p, uint32_t parity) {
   ExtendJob<COUNT> job = {p, sc, lens_c, lens_s, blocks_c, grab, parity, nullptr, 0, 0, false, 0, false};
   trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
                              blocks_c + queue_blocks(longest_s, grab), job, &ctr, rrt_trace_stack);
-  flush_counters<COUNT>(p.stats, ctr);
+  flush_counters<COUNT>(p.stats, 1, ctr);
 }
 
 // ---------------------------------------------------------------- primary
@@ -536,7 +537,7 @@ __global__ void RRT_TRACE_BOUNDS k_primary(RenderParams p, CameraParams cam, uin
   PrimaryJob<COUNT> job = {p, cam, sc, grab, single != 0 && p.filter_table == nullptr, 0, 0, 0, 0, 0, false};
   trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
                              (p.n_slots + grab - 1) / grab, job, &ctr, rrt_trace_stack);
-  flush_counters<COUNT>(p.stats, ctr);
+  flush_counters<COUNT>(p.stats, 0, ctr);
 }
 
 // ---------------------------------------------------------------- shade
@@ -746,7 +747,7 @@ __global__ void RRT_TRACE_BOUNDS k_connect(RenderParams p) {
   ConnectJob job = {p, sc, lens, grab, nullptr, 0, 0, 0, -1, -1, 0.0f, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
   trace_stream<true, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkConnect, 0),
                             queue_blocks(longest, grab), job, &ctr, rrt_trace_stack);
-  flush_counters<COUNT>(p.stats, ctr);
+  flush_counters<COUNT>(p.stats, 2, ctr);
 }
 
 // ---------------------------------------------------------------- film

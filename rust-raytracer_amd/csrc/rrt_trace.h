@@ -188,6 +188,7 @@ struct Ray {
   } while (0)
 #define RRT_NODE_STEP(lx, ly, lz, hx, hy, hz, ch)                                        \
   do {                                                                                   \
+    RRT_DBG_STEP();                                                                      \
     if (COUNT) ctr->nodes++;                                                             \
     float t0 = slab(r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, tmin, tmax);                  \
     float t1 = slab(r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, tmin, tmax);                  \
@@ -236,12 +237,28 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
 #ifdef RRT_PHASE_CLOCKS
   unsigned long long dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long clk2 = 0;
+  uint32_t lane_steps = 0;
   const unsigned long long clk_begin = RRT_CLK();
   unsigned long long clk = clk_begin;
 #endif
 
+#ifdef RRT_PHASE_CLOCKS
+#define RRT_DBG_RAY_BEGIN() lane_steps = 0
+#define RRT_DBG_STEP() ++lane_steps
+#define RRT_DBG_RAY_END()                                                                              \
+  do {                                                                                                 \
+    atomicMax(&rrt_phase_dbg[(ANY ? 16 : 0) + 13], (unsigned long long)lane_steps);                     \
+    if (lane_steps > 256) atomicAdd(&rrt_phase_dbg[(ANY ? 16 : 0) + 14], 1ull);                         \
+    if (lane_steps > 1024) atomicAdd(&rrt_phase_dbg[(ANY ? 16 : 0) + 15], 1ull);                        \
+  } while (0)
+#else
+#define RRT_DBG_RAY_BEGIN() do { } while (0)
+#define RRT_DBG_STEP() do { } while (0)
+#define RRT_DBG_RAY_END() do { } while (0)
+#endif
 #define RRT_START_RAY(ray)                                   \
   do {                                                       \
+    RRT_DBG_RAY_BEGIN();                                     \
     r = prepare_ray((ray).o, (ray).d);                       \
     tmin = (ray).tmin;                                       \
     tmax = (ray).tmax;                                       \
@@ -273,6 +290,7 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
     bool done = false;
     uint32_t done_block = 0;
     if (state == kArrived) {
+      RRT_DBG_RAY_END();
       Ray ray;
       if (job.advance(found, hit, r, &ray)) RRT_START_RAY(ray);
       else state = kJobDone;
@@ -454,7 +472,7 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
 #ifdef RRT_PHASE_CLOCKS
   if (lane == 0) {
     dbg[8] = RRT_CLK() - clk_begin;
-    for (int i = 0; i < 16; ++i) atomicAdd(&rrt_phase_dbg[(ANY ? 16 : 0) + i], dbg[i]);
+    for (int i = 0; i < 13; ++i) atomicAdd(&rrt_phase_dbg[(ANY ? 16 : 0) + i], dbg[i]);
   }
 #endif
 #undef RRT_START_RAY
