@@ -444,7 +444,7 @@ __global__ void RRT_TRACE_BOUNDS k_extend(RenderParams p, uint32_t parity) {
   TraceCounters ctr = {0, 0};
   ExtendJob<COUNT> job = {p, sc, lens_c, lens_s, blocks_c, grab, parity, nullptr, 0, 0, false, 0, false};
   trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
-                             blocks_c + queue_blocks(longest_s, grab), job, &ctr, rrt_trace_stack);
+                             blocks_c + queue_blocks(longest_s, grab), RRT_REFILL_QUORUM, job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, 1, ctr);
 }
 
@@ -536,7 +536,7 @@ __global__ void RRT_TRACE_BOUNDS k_primary(RenderParams p, CameraParams cam, uin
   TraceCounters ctr = {0, 0};
   PrimaryJob<COUNT> job = {p, cam, sc, grab, single != 0 && p.filter_table == nullptr, 0, 0, 0, 0, 0, false};
   trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
-                             (p.n_slots + grab - 1) / grab, job, &ctr, rrt_trace_stack);
+                             (p.n_slots + grab - 1) / grab, RRT_REFILL_QUORUM_COHERENT, job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, 0, ctr);
 }
 
@@ -746,7 +746,7 @@ __global__ void RRT_TRACE_BOUNDS k_connect(RenderParams p) {
   TraceCounters ctr = {0, 0};
   ConnectJob job = {p, sc, lens, grab, nullptr, 0, 0, 0, -1, -1, 0.0f, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
   trace_stream<true, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkConnect, 0),
-                            queue_blocks(longest, grab), job, &ctr, rrt_trace_stack);
+                            queue_blocks(longest, grab), RRT_REFILL_QUORUM, job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, 2, ctr);
 }
 
@@ -875,7 +875,8 @@ __global__ void RRT_TRACE_BOUNDS k_intersect(const BvhNode* nodes, const TriIsec
   sc = shapes_to_lds(sc, rrt_shape_words);
   TraceCounters ctr = {0, 0};
   IntersectJob job = {tris, sc, org_dir, prim_id, t_out, n, 0, 0};
-  trace_stream<false, false>(nodes, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, job, &ctr, rrt_trace_stack);
+  trace_stream<false, false>(nodes, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, RRT_REFILL_QUORUM, job, &ctr,
+                             rrt_trace_stack);
 }
 
 struct OccludedJob {
@@ -921,7 +922,8 @@ __global__ void RRT_TRACE_BOUNDS k_occluded(const BvhNode* nodes, const TriIsect
   sc = shapes_to_lds(sc, rrt_shape_words);
   TraceCounters ctr = {0, 0};
   OccludedJob job = {sc, odt, out, n, 0, 0, 0.0f};
-  trace_stream<true, false>(nodes, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, job, &ctr, rrt_trace_stack);
+  trace_stream<true, false>(nodes, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, RRT_REFILL_QUORUM, job, &ctr,
+                            rrt_trace_stack);
 }
 
 }  // namespace rrt

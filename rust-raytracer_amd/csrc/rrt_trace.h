@@ -164,14 +164,21 @@ struct Ray {
 // Two step schemes.  Closest hit: the lanes at inner nodes step together until 1 in
 // RRT_LEAF_FRACTION of the travelling lanes have reached a leaf, then those test their triangles
 // (the while-while scheme, without making every lane wait for the last straggler to arrive at a
-// leaf).  Any hit, whose step has less arithmetic in it: every trip steps every lane once, node or
+// leaf; 2 measured best, 4 and 8 lose 3-5 %, 1 -- plain while-while -- 20 %).  Any hit, whose step has less arithmetic in it: every trip steps every lane once, node or
 // triangle, with both kinds of load in flight together.  Measured: each scheme loses 15-20% on
 // the other kind of ray.
+// Lanes that must have arrived before a wave stops to hand in results and refill (`refill_quorum`):
+// a refill costs a memory round trip or two for the whole wave, an idle lane costs its share of
+// every step.  Scattered rays finish at very different times: 32 of 64.  Camera rays of neighbouring
+// samples finish almost together: 56.  (Measured optima; 16 and 48 lose 2-3 % on scattered rays.)
 #ifndef RRT_REFILL_QUORUM
 #define RRT_REFILL_QUORUM 32
 #endif
+#ifndef RRT_REFILL_QUORUM_COHERENT
+#define RRT_REFILL_QUORUM_COHERENT 56
+#endif
 #ifndef RRT_LEAF_FRACTION
-#define RRT_LEAF_FRACTION 4
+#define RRT_LEAF_FRACTION 2
 #endif
 
 // One inner-node step of a lane: the four child boxes against the ray, nearest child next, the
@@ -213,7 +220,7 @@ struct Ray {
 
 template <bool ANY, bool COUNT, class Job>
 RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __restrict__ tris, bool has_tris,
-                          uint32_t* work_cursor, uint32_t n_blocks, Job& job, TraceCounters* ctr,
+                          uint32_t* work_cursor, uint32_t n_blocks, int refill_quorum, Job& job, TraceCounters* ctr,
                           int2* lds_stack) {
   enum { kIdle = 0, kTravelling = 1, kArrived = 2, kJobDone = 3 };
   // this thread's column: the two words of entry e at lds[e * 2 * kTraceBlock + {0, 1}]
@@ -412,7 +419,7 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
           else RRT_POP_OR_ARRIVE();
         }
         const unsigned long long arrived = __ballot(state == kArrived);
-        if (__ballot(state == kTravelling) == 0 || __popcll(arrived) >= RRT_REFILL_QUORUM) break;
+        if (__ballot(state == kTravelling) == 0 || __popcll(arrived) >= refill_quorum) break;
       }
 #ifdef RRT_PHASE_CLOCKS
       { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(1, now - clk); clk = now; }
@@ -465,7 +472,7 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
         { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(2, now - clk); clk = now; }
 #endif
         const unsigned long long arrived = __ballot(state == kArrived);
-        if (__ballot(state == kTravelling) == 0 || __popcll(arrived) >= RRT_REFILL_QUORUM) break;
+        if (__ballot(state == kTravelling) == 0 || __popcll(arrived) >= refill_quorum) break;
       }
     }
   }
