@@ -457,7 +457,8 @@ int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   if (sd->n_rects > RRT_MAX_RECTS || sd->n_planes > RRT_MAX_PLANES || sd->n_spheres > RRT_MAX_SPHERES ||
       sd->n_lights > RRT_MAX_LIGHTS)
     return fail(ctx, RRT_E_UNSUPPORTED, "too many analytic shapes or lights for the device tables");
-  if (sd->n_tris >= (1u << 29)) return fail(ctx, RRT_E_UNSUPPORTED, "more than 2^29 triangles");
+  // object numbers share a word with two or three flag bits (leaf references, shadow records)
+  if (sd->n_tris >= (1u << 29) - 64) return fail(ctx, RRT_E_UNSUPPORTED, "more than 2^29 - 64 triangles");
   if (sd->rect_aabb_mode > RRT_RECT_AABB_OFF) return fail(ctx, RRT_E_INVALID, "bad rect_aabb_mode");
   for (uint32_t i = 0; i < sd->n_tris; ++i)
     if (sd->tri_mat[i] >= sd->n_materials) return fail(ctx, RRT_E_INVALID, "triangle material index out of range");

@@ -174,6 +174,9 @@ struct Ray {
 #ifndef RRT_REFILL_QUORUM
 #define RRT_REFILL_QUORUM 32
 #endif
+#ifndef RRT_ANY_UNIFIED
+#define RRT_ANY_UNIFIED 1
+#endif
 #ifndef RRT_REFILL_QUORUM_COHERENT
 #define RRT_REFILL_QUORUM_COHERENT 56
 #endif
@@ -371,7 +374,7 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
     }
 
     // ---- traversal until enough lanes have arrived to make a refill worth its cost
-    if (ANY) {
+    if (ANY && RRT_ANY_UNIFIED) {
       // One step per lane per trip: a lane at an inner node tests its four child boxes, a lane at
       // a leaf tests ONE of the leaf's triangles.  Both kinds of load are issued before either is
       // waited for, so a trip costs one memory round trip whatever the mix of lanes -- the round
