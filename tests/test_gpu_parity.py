@@ -291,7 +291,7 @@ def test_reconstruction_filters(rrt, oracle_binding, mixed, gpu_ctx, method, rad
         dev = gpu_ctx.film_download().astype(np.float64)
     finally:
         gpu_ctx.set_filter(rrt.FILTER_NONE)
-        gpu_ctx.set_option(rrt.OPT_MAX_SLOTS, 32 << 20)
+        gpu_ctx.set_option(rrt.OPT_MAX_SLOTS, 0)
     orc = oracle_binding.Oracle(scene.desc())
     orc.set_camera(cam)
     orc.set_filter(method, radius)
@@ -350,8 +350,52 @@ def test_crop_and_sample_ranges(rrt, cornell, gpu_ctx):
         gpu_ctx.render(s, 0, 8)
         small = gpu_ctx.film_download()
     finally:
-        gpu_ctx.set_option(rrt.OPT_MAX_SLOTS, 32 << 20)
+        gpu_ctx.set_option(rrt.OPT_MAX_SLOTS, 0)
     np.testing.assert_allclose(small, whole, rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_schedule_independence(rrt, buddha, gpu_ctx):
+    """The bench frame size (1920 x 1080) on the buddha scene: the film must not depend on how the
+    samples are scheduled -- all 24 in flight at once, 4 slots per pixel that each work through 6
+    samples (paths regenerated in place), or a pool so small that the window takes several passes --
+    and sample ranges must compose.  Differences are float summation order only."""
+    scene, rs = buddha
+    w, h, spp = 1920, 1080, 24
+    cam = rrt.Camera.from_settings(rs, w, h)
+    s = rrt.make_settings(w, h, rs.depth_limit, rs.clamp, seed=11)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    gpu_ctx.reset_stats()
+    gpu_ctx.render(s, 0, spp)
+    whole = gpu_ctx.film_download().astype(np.float64)
+    st = gpu_ctx.stats()
+    assert st.paths == w * h * spp and (whole[..., 3] == spp).all()
+    assert np.isfinite(whole).all() and whole[..., :3].min() >= 0 and whole[..., :3].max() <= spp * rs.clamp * 1.0001
+    films = {}
+    try:
+        gpu_ctx.set_option(rrt.OPT_BATCH_SAMPLES, 4)
+        gpu_ctx.film_clear()
+        gpu_ctx.render(s, 0, spp)
+        films["regenerated"] = gpu_ctx.film_download().astype(np.float64)
+        gpu_ctx.set_option(rrt.OPT_BATCH_SAMPLES, 0)
+        gpu_ctx.set_option(rrt.OPT_MAX_SLOTS, 3 << 20)  # 1080p has 2.07 M pixels: one slot per pixel, 24 samples each
+        gpu_ctx.film_clear()
+        gpu_ctx.render(s, 0, spp)
+        films["small pool"] = gpu_ctx.film_download().astype(np.float64)
+        gpu_ctx.set_option(rrt.OPT_MAX_SLOTS, 1 << 20)  # fewer slots than pixels: tile ranges
+        gpu_ctx.film_clear()
+        gpu_ctx.render(s, 0, 5)
+        gpu_ctx.render(s, 5, spp)
+        films["tile ranges, two calls"] = gpu_ctx.film_download().astype(np.float64)
+    finally:
+        gpu_ctx.set_option(rrt.OPT_BATCH_SAMPLES, 0)
+        gpu_ctx.set_option(rrt.OPT_MAX_SLOTS, 0)
+    for name, f in films.items():
+        np.testing.assert_array_equal(f[..., 3], whole[..., 3])
+        rel = np.abs(f[..., :3] - whole[..., :3]).max() / whole[..., :3].max()
+        print("%s: max difference %.3g of the film's maximum" % (name, rel))
+        assert rel <= 1e-5, name
 
 
 def test_empty_and_degenerate_inputs(rrt, cornell, gpu_ctx):
