@@ -398,6 +398,36 @@ def test_full_size_schedule_independence(rrt, buddha, gpu_ctx):
         assert rel <= 1e-5, name
 
 
+def test_cpp_host_render(rrt, cornell, gpu_ctx, tmp_path):
+    """The C++ host (Scene::load_from_folder, RenderSettingsFile, Camera, render() with its worker
+    thread and ThreadMessage channel, Film::merge_accumulators, tone map, PPM / PFM writers) drives
+    the same device library: scenes/cornell as shipped (1000 x 1000, depth 8), 2 samples, against
+    the film rendered through the ctypes layer with the same seed."""
+    import ctypes as C
+    scene, rs = cornell
+    prefix = str(tmp_path / "cornell")
+    rate = C.c_double()
+    dev = (C.c_int * 1)(0)
+    rc = rrt.host_lib().rrth_render_folder(os.fsencode(os.path.join(rrt.SCENES, "cornell")), dev, 1, 7, 2,
+                                           os.fsencode(prefix), C.byref(rate))
+    assert rc == 0, rrt.host_lib().rrth_last_error().decode()
+    assert rate.value > 1e6
+    w, h = rs.image_width, rs.image_height
+    with open(prefix + ".ppm", "rb") as f:
+        assert f.readline() == b"P6\n" and f.readline() == b"%d %d\n" % (w, h) and f.readline() == b"255\n"
+        ppm = np.frombuffer(f.read(), dtype=np.uint8).reshape(h, w, 3)
+    with open(prefix + ".pfm", "rb") as f:
+        assert f.readline() == b"PF\n" and f.readline() == b"%d %d\n" % (w, h) and f.readline() == b"-1.0\n"
+        pfm = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)[::-1]
+    film, cam, s = _device_film(rrt, gpu_ctx, scene, rs, w, h, 2, rs.depth_limit, 7)
+    mean = film[..., :3] / film[..., 3:4]
+    np.testing.assert_allclose(pfm, mean, rtol=1e-5, atol=1e-6)
+    ref = rrt.tonemap(film.astype(np.float32))
+    d = np.abs(ppm.astype(int) - ref.astype(int))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    assert ppm.mean() > 10
+
+
 def test_empty_and_degenerate_inputs(rrt, cornell, gpu_ctx):
     scene, rs = cornell
     # a scene with no triangles at all: only a quad light
