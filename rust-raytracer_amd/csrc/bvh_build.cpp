@@ -51,7 +51,10 @@ struct Node2 {
 };
 
 constexpr int kBins = 16;
-constexpr uint32_t kMaxLeaf = 4;
+#ifndef RRT_MAX_LEAF
+#define RRT_MAX_LEAF 4
+#endif
+constexpr uint32_t kMaxLeaf = RRT_MAX_LEAF;  // at most 4: a leaf reference keeps count - 1 in two bits
 constexpr uint32_t kSahDepthLimit = 40;     // below this depth splits fall back to the object median
 constexpr uint32_t kSpawnThreshold = 1u << 16;
 

@@ -1,5 +1,5 @@
 // C ABI of librrt_hip.so (include/rrt.h): context, scene upload, camera, film,
-// the per-batch launch sequence of the wavefront path tracer, parity hooks,
+// the launch sequence of a pass of the streaming wavefront path tracer, parity hooks,
 // statistics and the single-process RCCL film reduce.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -780,8 +780,8 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
   }
   uint32_t k = ctx->batch_samples ? ctx->batch_samples : (uint32_t)std::min<uint64_t>(kMaxSlotsPerPixel, std::max<uint64_t>(1, max_slots / (total_tiles * 64)));
   k = std::min(k, n_samples);
-  const uint32_t tiles_per_batch = (uint32_t)std::min<uint64_t>(total_tiles, std::max<uint64_t>(1, max_slots / (64ull * k)));
-  rc = ensure_state(ctx, tiles_per_batch * 64 * k, s->depth_limit, need_mis);
+  const uint32_t tiles_per_pass = (uint32_t)std::min<uint64_t>(total_tiles, std::max<uint64_t>(1, max_slots / (64ull * k)));
+  rc = ensure_state(ctx, tiles_per_pass * 64 * k, s->depth_limit, need_mis);
   if (rc != RRT_OK) return rc;
 
   RenderParams p;
@@ -807,9 +807,9 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
   p.clamp = (float)s->clamp;
   p.filter_table = ctx->filter_method != RRT_FILTER_NONE ? ctx->d_filter_table : nullptr;
   p.filter_radius = ctx->filter_radius;
-  for (uint64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_batch) {
+  for (uint64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_pass) {
     p.tile_begin = (uint32_t)t0;
-    p.n_tiles = (uint32_t)std::min<uint64_t>(tiles_per_batch, total_tiles - t0);
+    p.n_tiles = (uint32_t)std::min<uint64_t>(tiles_per_pass, total_tiles - t0);
     p.sample_begin = sample_begin;
     p.sample_end = sample_end;
     p.n_samples = k;

@@ -19,8 +19,9 @@
 // A slot belongs to one pixel for the whole render and works through that pixel's samples
 // k, k + K, k + 2K, ... one path after the other; when a path ends the slot starts the next one in
 // the following iteration, so every launch stays as wide as the pool until the samples run out.
-// (Running a batch of paths to completion instead leaves a dozen launches per batch that wait on
-// the few longest paths with the machine nearly empty: that was 2/3 of the frame time.)
+// The host makes the pool as large as memory allows, up to K = one slot per sample (then no slot
+// ever starts a second path): the dozen last iterations of a pass hold few paths and each waits
+// for its longest rays, a fixed cost that only a large pool makes small.
 // The result does not depend on the schedule: a path is a function of (seed, pixel, sample), a
 // slot adds its finished paths in sample order, and film adds a pixel's slots in slot order.
 //
