@@ -325,6 +325,7 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
   const uint32_t trace_grid = std::min(grid_all + 1, kTraceGridBlocks);
   int rc;
   const uint32_t per_slot = (p.sample_end - p.sample_begin + p.n_samples - 1) / p.n_samples;
+  p.single = per_slot == 1 && !p.filter_table ? 1u : 0u;
   // a slot needs at least one iteration per sample plus one to retire, at most depth_limit per sample
   const uint64_t max_iterations = (uint64_t)per_slot * p.depth_limit + 2;
   uint64_t it = 0;
@@ -336,10 +337,9 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
       HIP_TRY(ctx, hipMemsetAsync(p.a.counters + row_words * 2 * next, 0, row_bytes * kRowsPerIteration, ctx->stream));
       if (it == 0) {
         // the first camera ray of every slot: generated and traced by one kernel
-        const uint32_t single = per_slot == 1 ? 1u : 0u;
         if ((rc = record_begin(ctx, 5)) != RRT_OK) return rc;
-        if (ctx->count_traversal) hipLaunchKernelGGL(k_primary<true>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, single);
-        else hipLaunchKernelGGL(k_primary<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, single);
+        if (ctx->count_traversal) hipLaunchKernelGGL(k_primary<true>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera);
+        else hipLaunchKernelGGL(k_primary<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera);
         if ((rc = record_end(ctx)) != RRT_OK) return rc;
       } else {
         if ((rc = record_begin(ctx, 0)) != RRT_OK) return rc;

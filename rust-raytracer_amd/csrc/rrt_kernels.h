@@ -132,6 +132,10 @@ struct RenderParams {
   float clamp;
   const float* filter_table;  // 16 x 16 weights, or null: every sample lands in its own pixel with weight 1
   double filter_radius;
+  // One sample per slot and no reconstruction filter: a slot's radiance is its pixel's sample, so
+  // nothing is banked -- film reads `radiance` directly, a path that ends just stops, and the
+  // start queue only sees rays that escaped after a specular bounce (they still owe the environment).
+  uint32_t single;
 };
 
 RRT_DEV uint32_t* counter_at(uint32_t* counters, uint32_t row, uint32_t seg) {
@@ -319,42 +323,53 @@ __global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam,
       slot = entry & kSlotMask;
       uint32_t x, y, k;
       slot_pixel(p, slot, &x, &y, &k);
-      float4 l4;
-      if (entry & kEscaped) {
+      if (p.single) {
+        // only rays that escaped after a specular bounce come here (src/tracer.rs:44-63): they
+        // still owe the environment; nothing is banked and no slot starts a second path
         const float4 d = p.a.ray_d[slot];
-        const uint32_t state = __float_as_uint(d.w);
-        if (state == 0u) {
-          // a camera ray that escapes sees the lights' environment term (src/tracer.rs:50-53)
-          l4 = f4(escape_radiance(p.scene, p.env, mk(d)), 0.0f);
+        const V3 le = escape_radiance(p.scene, p.env, mk(d));
+        const float4 b = p.a.beta[slot];
+        float4 l4 = p.a.radiance[slot];
+        l4.x += b.x * le.x; l4.y += b.y * le.y; l4.z += b.z * le.z;
+        p.a.radiance[slot] = l4;
+      } else {
+        float4 l4;
+        if (entry & kEscaped) {
+          const float4 d = p.a.ray_d[slot];
+          const uint32_t state = __float_as_uint(d.w);
+          if (state == 0u) {
+            // a camera ray that escapes sees the lights' environment term (src/tracer.rs:50-53)
+            l4 = f4(escape_radiance(p.scene, p.env, mk(d)), 0.0f);
+          } else {
+            l4 = p.a.radiance[slot];
+            if (state & 1u) {  // later rays only after a specular bounce (src/tracer.rs:44-63)
+              const V3 le = escape_radiance(p.scene, p.env, mk(d));
+              const float4 b = p.a.beta[slot];
+              l4.x += b.x * le.x; l4.y += b.y * le.y; l4.z += b.z * le.z;
+            }
+          }
         } else {
           l4 = p.a.radiance[slot];
-          if (state & 1u) {  // later rays only after a specular bounce (src/tracer.rs:44-63)
-            const V3 le = escape_radiance(p.scene, p.env, mk(d));
-            const float4 b = p.a.beta[slot];
-            l4.x += b.x * le.x; l4.y += b.y * le.y; l4.z += b.z * le.z;
-          }
         }
-      } else {
-        l4 = p.a.radiance[slot];
-      }
-      const uint32_t finished = p.a.sample[slot];
-      if (p.filter_table) {
-        // the film position is the camera sample's (src/sampler.rs:76-83): pixel + draws 0, 1 of block 0
-        const Rng4 r = rng_block(p.seed, y * p.width + x, finished, 0);
-        splat_filtered(p, (double)x + (double)r.u[0], (double)y + (double)r.u[1], l4.x, l4.y, l4.z);
-      } else {
-        // the slot's first finished path initialises its sum, so the array needs no clearing pass
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (finished != p.sample_begin + k) acc = p.a.accum[slot];
-        acc.x += l4.x; acc.y += l4.y; acc.z += l4.z; acc.w += 1.0f;
-        p.a.accum[slot] = acc;
-      }
-      const uint32_t sample = finished + p.n_samples;
-      if (sample < p.sample_end) {
-        const Rng4 r = rng_block(p.seed, y * p.width + x, sample, 0);
-        camera_ray(cam, x, y, r, &org, &dir);
-        p.a.sample[slot] = sample;
-        started = true;
+        const uint32_t finished = p.a.sample[slot];
+        if (p.filter_table) {
+          // the film position is the camera sample's (src/sampler.rs:76-83): pixel + draws 0, 1 of block 0
+          const Rng4 r = rng_block(p.seed, y * p.width + x, finished, 0);
+          splat_filtered(p, (double)x + (double)r.u[0], (double)y + (double)r.u[1], l4.x, l4.y, l4.z);
+        } else {
+          // the slot's first finished path initialises its sum, so the array needs no clearing pass
+          float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (finished != p.sample_begin + k) acc = p.a.accum[slot];
+          acc.x += l4.x; acc.y += l4.y; acc.z += l4.z; acc.w += 1.0f;
+          p.a.accum[slot] = acc;
+        }
+        const uint32_t sample = finished + p.n_samples;
+        if (sample < p.sample_end) {
+          const Rng4 r = rng_block(p.seed, y * p.width + x, sample, 0);
+          camera_ray(cam, x, y, r, &org, &dir);
+          p.a.sample[slot] = sample;
+          started = true;
+        }
       }
     }
     ray_queue_push(p, p.a.rays_camera, kRowCamera, chunk, started, slot, org, dir, 0u);
@@ -385,7 +400,7 @@ struct ExtendJob {
   uint32_t slot, state;
   bool hit_surface;
   uint32_t out_slot;   // result of the retired job, until the flush
-  bool out_hit;
+  bool out_hit, out_owes;  // owes: the escaped ray still has something to collect in start
 
   RRT_DEV uint32_t open_block(uint32_t j) {
     uint32_t n;
@@ -419,10 +434,11 @@ struct ExtendJob {
   RRT_DEV void retire() {
     out_slot = slot;
     out_hit = hit_surface;
+    out_owes = !p.single || (state & 1u);
   }
   // Two queues, two atomics: both issued before either result is used.
   RRT_DEV void flush(bool done, uint32_t block) {
-    const bool to_shade = done && out_hit, to_start = done && !out_hit;
+    const bool to_shade = done && out_hit, to_start = done && !out_hit && out_owes;
     const unsigned long long mask_h = __ballot(to_shade), mask_m = __ballot(to_start);
     const int lane = threadIdx.x & 63;
     const int leader_h = mask_h ? __ffsll((long long)mask_h) - 1 : 0, leader_m = mask_m ? __ffsll((long long)mask_m) - 1 : 0;
@@ -450,7 +466,7 @@ __global__ void RRT_TRACE_BOUNDS k_extend(RenderParams p, uint32_t parity) {
   const uint32_t grab = grab_size(longest_c + longest_s, gridDim.x * (kTraceBlock / 64));
   const uint32_t blocks_c = queue_blocks(longest_c, grab);
   TraceCounters ctr = {0, 0};
-  ExtendJob<COUNT> job = {p, sc, lens_c, lens_s, blocks_c, grab, parity, nullptr, 0, 0, false, 0, false};
+  ExtendJob<COUNT> job = {p, sc, lens_c, lens_s, blocks_c, grab, parity, nullptr, 0, 0, false, 0, false, false};
   trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
                              blocks_c + queue_blocks(longest_s, grab), RRT_REFILL_QUORUM, job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, 1, ctr);
@@ -467,7 +483,7 @@ struct PrimaryJob {
   const CameraParams& cam;
   const SceneTables* sc;  // LDS copy of the shapes
   uint32_t grab;
-  bool single;            // one sample per slot and no reconstruction filter
+  bool single;            // RenderParams::single
   uint32_t base, slot;
   int kind;               // 0 nothing to hand in, 1 to shade, 2 to start (escaped)
   uint32_t out_slot;      // result of the retired job, until the flush
@@ -503,8 +519,8 @@ struct PrimaryJob {
       kind = 1;
     } else if (single) {
       // a camera ray that escapes sees the lights' environment term (src/tracer.rs:50-53): the
-      // slot's only path is complete, and its sum is that radiance
-      p.a.accum[slot] = f4(escape_radiance(p.scene, p.env, r.d), 1.0f);
+      // slot's only path is complete
+      p.a.radiance[slot] = f4(escape_radiance(p.scene, p.env, r.d), 0.0f);
       kind = 0;
     } else {
       p.a.ray_d[slot] = f4(r.d, __uint_as_float(0u));
@@ -536,13 +552,13 @@ struct PrimaryJob {
 };
 
 template <bool COUNT>
-__global__ void RRT_TRACE_BOUNDS k_primary(RenderParams p, CameraParams cam, uint32_t single) {
+__global__ void RRT_TRACE_BOUNDS k_primary(RenderParams p, CameraParams cam) {
   RRT_DECLARE_TRACE_STACK();
   RRT_DECLARE_SHAPES();
   const SceneTables* sc = shapes_to_lds(p.scene, rrt_shape_words);
   const uint32_t grab = grab_size((p.n_slots + kSegments - 1) / kSegments, gridDim.x * (kTraceBlock / 64));
   TraceCounters ctr = {0, 0};
-  PrimaryJob<COUNT> job = {p, cam, sc, grab, single != 0 && p.filter_table == nullptr, 0, 0, 0, 0, 0, false};
+  PrimaryJob<COUNT> job = {p, cam, sc, grab, p.single != 0, 0, 0, 0, 0, 0, false};
   trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
                              (p.n_slots + grab - 1) / grab, RRT_REFILL_QUORUM_COHERENT, job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, 0, ctr);
@@ -654,7 +670,7 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
     if (has_work) p.a.sh_c[slot] = f4(light_c, __uint_as_float(flags | ((uint32_t)prim << 3)));
   }
   ray_queue_push(p, p.a.rays_cont[next], row_cont(next), chunk, survive, slot, next_o, next_d, next_state);
-  queue_push(p, p.a.q_start[next], row_start(next), chunk, active && !survive, slot);
+  queue_push(p, p.a.q_start[next], row_start(next), chunk, active && !survive && !p.single, slot);
   queue_push(p, p.a.q_shadow, kRowShadow, chunk, has_work, slot);
   counter_add(p, kRowBounces, chunk, active);
   counter_add(p, kRowMisRays, chunk, has_mis);
@@ -774,10 +790,11 @@ __global__ void __launch_bounds__(256) k_film(RenderParams p, uint32_t group) {
   const bool live = pix < p.n_tiles * 64 && slot_pixel(p, pix * p.n_samples, &x, &y, &k);
   float r = 0.0f, gr = 0.0f, b = 0.0f, w = 0.0f;
   if (live) {
-    const float4* acc = p.a.accum + (size_t)pix * p.n_samples;
+    // with one sample per slot the slot's radiance is the sample (weight 1): nothing was banked
+    const float4* acc = (p.single ? p.a.radiance : p.a.accum) + (size_t)pix * p.n_samples;
     for (uint32_t s = g; s < p.n_samples; s += group) {
       const float4 v = acc[s];
-      r += v.x; gr += v.y; b += v.z; w += v.w;
+      r += v.x; gr += v.y; b += v.z; w += p.single ? 1.0f : v.w;
     }
   }
   for (uint32_t d = group >> 1; d > 0; d >>= 1) {
