@@ -51,6 +51,9 @@ struct Node2 {
 };
 
 constexpr int kBins = 16;
+#ifndef RRT_SAH_NODE_COST
+#define RRT_SAH_NODE_COST 1.0  // cost of a traversal step in units of one triangle test
+#endif
 #ifndef RRT_MAX_LEAF
 #define RRT_MAX_LEAF 4
 #endif
@@ -149,7 +152,7 @@ struct Builder {
       if (best_axis >= 0) {
         // leaf cost n * A versus 1 traversal step + children
         const float parent_area = bounds.half_area();
-        const float split_cost = 1.0f + (parent_area > 0.0f ? best_cost / parent_area : 0.0f);
+        const float split_cost = (float)RRT_SAH_NODE_COST + (parent_area > 0.0f ? best_cost / parent_area : 0.0f);
         if (cnt <= kMaxLeaf && (float)cnt <= split_cost) { make_leaf(); return; }
         const float c0 = cbounds.mn[best_axis];
         const float scale = (float)kBins / (cbounds.mx[best_axis] - c0);

@@ -551,8 +551,10 @@ struct PrimaryJob {
   }
 };
 
+// (Bounded to 4 waves per SIMD = 128 registers: the kernel sits right at that edge, and one register
+// more would cost a quarter of its rays in flight.)
 template <bool COUNT>
-__global__ void RRT_TRACE_BOUNDS k_primary(RenderParams p, CameraParams cam) {
+__global__ void __launch_bounds__(kTraceBlock, 4) k_primary(RenderParams p, CameraParams cam) {
   RRT_DECLARE_TRACE_STACK();
   RRT_DECLARE_SHAPES();
   const SceneTables* sc = shapes_to_lds(p.scene, rrt_shape_words);

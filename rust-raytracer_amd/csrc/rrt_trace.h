@@ -232,6 +232,8 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
   const int lane = threadIdx.x & 63;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   uint32_t cursor = 0, end = 0, block = 0;  // wave-uniform: the index block being handed out
+  const uint32_t n_waves = gridDim.x * (blockDim.x >> 6), wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  bool first_block = true;
   bool exhausted = false;                   // wave-uniform: the global cursor has run past `total`
   int state = kIdle;
   uint32_t my_block = 0;
@@ -326,9 +328,18 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
       const unsigned long long idle_mask = __ballot(state == kIdle && !fresh);
       if (idle_mask == 0 || exhausted) break;
       if (cursor >= end) {
-        uint32_t g = 0;
-        if (lane == 0) g = atomicAdd(work_cursor, 1u);
-        g = __shfl(g, 0);
+        // A launch with no more blocks than waves hands them out by wave number and never touches
+        // the cursor: 8192 waves finding it exhausted one atomic at a time was a 90 us floor under
+        // every launch.  (Larger launches take every block from the cursor: waves that start late,
+        // when others have exited, must not be left holding blocks of their own.)
+        uint32_t g = n_blocks;
+        if (n_blocks <= n_waves) {
+          if (first_block) g = wave_id;
+        } else {
+          if (lane == 0) g = atomicAdd(work_cursor, 1u);
+          g = __shfl(g, 0);
+        }
+        first_block = false;
         if (g >= n_blocks) {
           exhausted = true;
           break;
