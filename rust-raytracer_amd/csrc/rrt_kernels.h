@@ -455,8 +455,9 @@ struct ExtendJob {
   }
 };
 
+// (Bounded to 5 waves per SIMD = 96 registers, which is what it uses: a guard against creeping over.)
 template <bool COUNT>
-__global__ void RRT_TRACE_BOUNDS k_extend(RenderParams p, uint32_t parity) {
+__global__ void __launch_bounds__(kTraceBlock, 5) k_extend(RenderParams p, uint32_t parity) {
   RRT_DECLARE_TRACE_STACK();
   RRT_DECLARE_SHAPES();
   const SceneTables* sc = shapes_to_lds(p.scene, rrt_shape_words);
