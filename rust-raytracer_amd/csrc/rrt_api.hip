@@ -778,11 +778,23 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
     max_slots = (uint64_t)(have * kAutoMemoryShare / (double)state_bytes(1u << 20, need_mis) * (double)(1u << 20));
     max_slots = std::min<uint64_t>(std::max<uint64_t>(max_slots, 1u << 16), kSlotLimit);
   }
-  uint32_t k = ctx->batch_samples ? ctx->batch_samples : (uint32_t)std::min<uint64_t>(kMaxSlotsPerPixel, std::max<uint64_t>(1, max_slots / (total_tiles * 64)));
-  k = std::min(k, n_samples);
-  const uint32_t tiles_per_pass = (uint32_t)std::min<uint64_t>(total_tiles, std::max<uint64_t>(1, max_slots / (64ull * k)));
-  rc = ensure_state(ctx, tiles_per_pass * 64 * k, s->depth_limit, need_mis);
-  if (rc != RRT_OK) return rc;
+  uint32_t k, tiles_per_pass;
+  for (;;) {
+    k = ctx->batch_samples ? ctx->batch_samples
+                           : (uint32_t)std::min<uint64_t>(kMaxSlotsPerPixel, std::max<uint64_t>(1, max_slots / (total_tiles * 64)));
+    k = std::min(k, n_samples);
+    tiles_per_pass = (uint32_t)std::min<uint64_t>(total_tiles, std::max<uint64_t>(1, max_slots / (64ull * k)));
+    rc = ensure_state(ctx, tiles_per_pass * 64 * k, s->depth_limit, need_mis);
+    // an automatic size that the allocator cannot deliver after all (fragmentation, another
+    // process on the device): try again with half
+    if (rc == RRT_E_NOMEM && ctx->max_slots == 0 && max_slots > (1u << 16)) {
+      free_state(ctx);
+      max_slots /= 2;
+      continue;
+    }
+    if (rc != RRT_OK) return rc;
+    break;
+  }
 
   RenderParams p;
   std::memset(&p, 0, sizeof(p));
