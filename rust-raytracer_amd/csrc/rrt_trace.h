@@ -30,7 +30,7 @@ constexpr int kSpillDepth = kStackDepth - kLdsDepth;
 // pointer the compiler folds "LDS or scratch?" into a select between two generic addresses and
 // issues flat loads, which take the slow path for both and wait on every counter.
 // The accesses are volatile for the same reason: a volatile load is never merged with the scratch one.
-typedef volatile __attribute__((address_space(3))) int* LdsStackWordPtr;
+typedef volatile __attribute__((address_space(3))) unsigned long long* LdsStackWordPtr;  // one entry: reference | distance bits << 32
 
 // The stack pointer is a plain local of the traversal loop, and the spill array a local of its
 // own: as members of one struct next to a dynamically indexed array they would all be placed in
@@ -38,9 +38,8 @@ typedef volatile __attribute__((address_space(3))) int* LdsStackWordPtr;
 #define RRT_STACK_PUSH(ref, t)                                                   \
   do {                                                                           \
     if (kLdsDepth > 0 && sp < kLdsDepth) {                                       \
-      const LdsStackWordPtr w_ = lds + sp * (2 * kTraceBlock);                   \
-      w_[0] = (ref);                                                             \
-      w_[1] = __float_as_int(t);                                                 \
+      lds[sp * kTraceBlock] = (unsigned long long)(unsigned)(ref) |              \
+                              ((unsigned long long)__float_as_uint(t) << 32);    \
     } else {                                                                     \
       spill[min(sp - kLdsDepth, kSpillDepth - 1)] = make_int2((ref), __float_as_int(t)); \
     }                                                                            \
@@ -50,9 +49,9 @@ typedef volatile __attribute__((address_space(3))) int* LdsStackWordPtr;
   do {                                                                           \
     --sp;                                                                        \
     if (kLdsDepth > 0 && sp < kLdsDepth) {                                       \
-      const LdsStackWordPtr w_ = lds + sp * (2 * kTraceBlock);                   \
-      (dst).x = w_[0];                                                           \
-      (dst).y = w_[1];                                                           \
+      const unsigned long long w_ = lds[sp * kTraceBlock];                       \
+      (dst).x = (int)(unsigned)w_;                                               \
+      (dst).y = (int)(unsigned)(w_ >> 32);                                       \
     }                                                                            \
     else (dst) = spill[min(sp - kLdsDepth, kSpillDepth - 1)];                    \
   } while (0)
@@ -226,8 +225,8 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
                           uint32_t* work_cursor, uint32_t n_blocks, int refill_quorum, Job& job, TraceCounters* ctr,
                           int2* lds_stack) {
   enum { kIdle = 0, kTravelling = 1, kArrived = 2, kJobDone = 3 };
-  // this thread's column: the two words of entry e at lds[e * 2 * kTraceBlock + {0, 1}]
-  const LdsStackWordPtr lds = (LdsStackWordPtr)lds_stack + 2 * threadIdx.x;
+  // this thread's column: entry e at lds[e * kTraceBlock]
+  const LdsStackWordPtr lds = (LdsStackWordPtr)lds_stack + threadIdx.x;
   int2 spill[kSpillDepth];
   const int lane = threadIdx.x & 63;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
