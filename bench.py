@@ -46,9 +46,9 @@ rrdist = _load("rust_raytracer_amd.distributed", "rust-raytracer_amd/distributed
 stress = _load("rust_raytracer_amd.stress", "rust-raytracer_amd/stress.py")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-# algorithmic bytes per ray: 112 B per BVH node visited (four child boxes of six f32 + four links), 36 B per
+# algorithmic bytes per ray: 64 B per BVH node visited (corner, grid exponents, four links, four boxes of six bytes), 36 B per
 # triangle tested (nine f32 positions), 32 B ray in, 16 B hit out
-NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 112, 36, 32, 16
+NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 64, 36, 32, 16
 
 
 def load_buddha(width, height):

@@ -229,6 +229,14 @@ int rrt_intersect(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_t* prim_
  * max_dist. */
 int rrt_occluded(rrt_ctx* ctx, const float* org_dir_tmax, uint32_t n, uint8_t* hit);
 
+/* Builds the hierarchy for n_tris triangles (host [n][3][3] positions) exactly as
+ * rrt_upload_scene would, on the host alone, and checks it: every triangle inside the
+ * (8-bit quantised) box of every node on the way to it, every triangle in exactly one
+ * leaf, depth within bounds.  Returns the number of violations (0 = sound) or a negative
+ * error code; optionally reports the node count and the depth.  No device is touched.
+ * Has no counterpart in the reference (its hierarchy is the bvh crate's): a self-check. */
+int64_t rrt_bvh_selfcheck(const float* tri_pos, uint32_t n_tris, uint32_t* n_nodes, uint32_t* max_depth);
+
 /* Options. */
 enum {
   RRT_OPT_TIMING = 1,          /* 1: time each kernel with HIP events (the host waits at the end of every pass) */

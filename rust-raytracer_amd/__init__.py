@@ -99,7 +99,7 @@ RRT_SYMBOLS = ["rrt_device_count", "rrt_create", "rrt_destroy", "rrt_set_stream"
                "rrt_set_camera", "rrt_film_alloc", "rrt_film_bind", "rrt_film_clear", "rrt_film_download",
                "rrt_film_device_ptr", "rrt_render", "rrt_synchronize", "rrt_film_reduce", "rrt_intersect",
                "rrt_occluded", "rrt_set_option", "rrt_get_stats", "rrt_reset_stats", "rrt_last_error",
-               "rrt_set_filter", "rrt_film_tonemap"]
+               "rrt_set_filter", "rrt_film_tonemap", "rrt_bvh_selfcheck"]
 RRTH_SYMBOLS = ["rrth_last_error", "rrth_scene_load", "rrth_scene_load_with_mesh", "rrth_scene_free",
                 "rrth_scene_desc", "rrth_scene_set_rect_aabb_mode", "rrth_scene_set_material",
                 "rrth_load_render_settings", "rrth_camera_matrices", "rrth_camera_generate_ray", "rrth_tonemap",
@@ -143,6 +143,8 @@ def hip_lib():
         lib.rrt_reset_stats.argtypes = [C.c_void_p]
         lib.rrt_last_error.argtypes = [C.c_void_p]
         lib.rrt_last_error.restype = C.c_char_p
+        lib.rrt_bvh_selfcheck.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        lib.rrt_bvh_selfcheck.restype = C.c_int64
         _hip = lib
     return _hip
 
@@ -369,6 +371,17 @@ def make_settings(width, height, depth_limit, clamp, seed=0, crop=None):
     s.clamp = clamp
     s.seed = seed
     return s
+
+
+def bvh_selfcheck(tri_pos):
+    """Builds the hierarchy rrt_upload_scene would build for these triangles ([n][3][3] float32) on the
+    host and checks its invariants: (violations, node count, depth).  Needs no GPU."""
+    pos = np.ascontiguousarray(tri_pos, dtype=np.float32).reshape(-1, 3, 3)
+    n_nodes, depth = C.c_uint32(0), C.c_uint32(0)
+    bad = hip_lib().rrt_bvh_selfcheck(pos.ctypes.data, pos.shape[0], C.byref(n_nodes), C.byref(depth))
+    if bad < 0:
+        raise RrtError("rrt_bvh_selfcheck failed: %d" % bad)
+    return int(bad), n_nodes.value, depth.value
 
 
 def tonemap(sum_rgbw):

@@ -39,7 +39,7 @@ def build_hip(force=False, extra_flags=()):
     deps = [os.path.join(CSRC, f) for f in HIP_SOURCES + HIP_HEADERS] + [os.path.join(ROOT, "include", "rrt.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", *extra_flags,
+        _run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-pthread", *extra_flags,
               "-o", out, *HIP_SOURCES, "-ldl"], CSRC)
     return out
 

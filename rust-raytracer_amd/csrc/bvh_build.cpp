@@ -252,15 +252,40 @@ struct Collapser {
     out.emplace_back();
     BvhNode node;
     std::memset(&node, 0, sizeof(node));
+    // the node's own box, and per axis the smallest power-of-two grid step that spans it in 255 steps
+    Box all = c[0].box;
+    for (int i = 1; i < n; ++i)
+      for (int k = 0; k < 3; ++k) {
+        all.mn[k] = std::min(all.mn[k], c[i].box.mn[k]);
+        all.mx[k] = std::max(all.mx[k], c[i].box.mx[k]);
+      }
+    const bool empty = !(all.mx[0] >= all.mn[0]);  // a scene without triangles
+    double step[3];
+    for (int k = 0; k < 3; ++k) {
+      node.origin[k] = empty ? 0.0f : all.mn[k];
+      const double extent = empty ? 0.0 : (double)all.mx[k] - (double)all.mn[k];
+      int e = -126;
+      if (extent > 0.0) {
+        int ex;
+        std::frexp(extent / 255.0, &ex);  // extent / 255 = m * 2^ex with m in [0.5, 1): 2^ex is at least as large
+        e = std::min(std::max(ex, -126), 127);
+      }
+      node.exp[k] = (uint8_t)(e + 127);
+      step[k] = std::ldexp(1.0, e);
+    }
     for (int i = 0; i < 4; ++i) {
-      if (i < n) {
-        node.lo_x[i] = c[i].box.mn[0]; node.lo_y[i] = c[i].box.mn[1]; node.lo_z[i] = c[i].box.mn[2];
-        node.hi_x[i] = c[i].box.mx[0]; node.hi_y[i] = c[i].box.mx[1]; node.hi_z[i] = c[i].box.mx[2];
+      if (i < n && !empty) {
+        for (int k = 0; k < 3; ++k) {
+          // differences of floats and divisions by a power of two are exact in double
+          const double lo = std::floor(((double)c[i].box.mn[k] - (double)node.origin[k]) / step[k]);
+          const double hi = std::ceil(((double)c[i].box.mx[k] - (double)node.origin[k]) / step[k]);
+          node.qlo[k][i] = (uint8_t)std::min(std::max(lo, 0.0), 255.0);
+          node.qhi[k][i] = (uint8_t)std::min(std::max(hi, 0.0), 255.0);
+        }
         node.child[i] = c[i].ref;  // inner references are patched below
       } else {
-        node.lo_x[i] = node.lo_y[i] = node.lo_z[i] = INFINITY;
-        node.hi_x[i] = node.hi_y[i] = node.hi_z[i] = -INFINITY;
-        node.child[i] = ~0;
+        for (int k = 0; k < 3; ++k) { node.qlo[k][i] = 255; node.qhi[k][i] = 0; }
+        node.child[i] = kAbsentChild;
       }
     }
     for (int i = 0; i < n; ++i)
@@ -339,6 +364,72 @@ bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuild
   out->order = order;
   out->max_depth = col.max_depth;
   return true;
+}
+
+namespace {
+
+// The box a traversing lane decodes for child i of a node, in double (every term is exact there).
+void decoded_box(const BvhNode& n, int i, double* mn, double* mx) {
+  for (int k = 0; k < 3; ++k) {
+    const double step = std::ldexp(1.0, (int)n.exp[k] - 127);
+    mn[k] = (double)n.origin[k] + n.qlo[k][i] * step;
+    mx[k] = (double)n.origin[k] + n.qhi[k][i] * step;
+  }
+}
+
+// Walks the hierarchy and checks what traversal relies on: every triangle lies inside the decoded
+// box of every ancestor's child slot that leads to it, every leaf slot is reached exactly once, and
+// no chain of inner nodes is longer than max_depth.
+struct Validator {
+  const float* pos;
+  const BvhBuildResult& b;
+  uint32_t n_tris;
+  std::vector<uint8_t> seen;
+  uint64_t bad = 0;
+
+  // Exact bounds of the triangles behind `ref` (depth = inner nodes on the way here, this one included).
+  void bounds(int32_t ref, uint32_t depth, double* mn, double* mx) {
+    for (int k = 0; k < 3; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
+    if (ref < 0) {
+      const uint32_t code = (uint32_t)~ref, first = code >> 2, cnt = (code & 3u) + 1u;
+      if ((uint64_t)first + cnt > n_tris) { ++bad; return; }
+      for (uint32_t t = first; t < first + cnt; ++t) {
+        if (seen[t]++) ++bad;
+        const float* p = pos + 9 * (size_t)b.order[t];
+        for (int v = 0; v < 3; ++v)
+          for (int k = 0; k < 3; ++k) {
+            mn[k] = std::min(mn[k], (double)p[3 * v + k]);
+            mx[k] = std::max(mx[k], (double)p[3 * v + k]);
+          }
+      }
+      return;
+    }
+    if ((uint32_t)ref >= b.n_nodes || depth > b.max_depth) { ++bad; return; }
+    const BvhNode& n = b.nodes[ref];
+    for (int i = 0; i < 4; ++i) {
+      if (n.child[i] == kAbsentChild) continue;
+      double cmn[3], cmx[3], dmn[3], dmx[3];
+      bounds(n.child[i], depth + (n.child[i] >= 0 ? 1 : 0), cmn, cmx);
+      decoded_box(n, i, dmn, dmx);
+      for (int k = 0; k < 3; ++k) {
+        if (!(cmn[k] >= dmn[k] && cmx[k] <= dmx[k])) ++bad;
+        mn[k] = std::min(mn[k], cmn[k]);
+        mx[k] = std::max(mx[k], cmx[k]);
+      }
+    }
+  }
+};
+
+}  // namespace
+
+uint64_t validate_bvh(const float* tri_pos, uint32_t n_tris, const BvhBuildResult& b) {
+  if (n_tris == 0 || b.n_nodes == 0) return 0;
+  Validator v{tri_pos, b, n_tris, std::vector<uint8_t>(n_tris, 0), 0};
+  double mn[3], mx[3];
+  v.bounds(0, 1, mn, mx);
+  for (uint32_t t = 0; t < n_tris; ++t)
+    if (v.seen[t] != 1) ++v.bad;
+  return v.bad;
 }
 
 void free_bvh(BvhBuildResult* r) {

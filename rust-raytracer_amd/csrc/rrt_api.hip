@@ -970,6 +970,17 @@ int rrt_get_stats(rrt_ctx* ctx, rrt_stats* out) {
   return RRT_OK;
 }
 
+int64_t rrt_bvh_selfcheck(const float* tri_pos, uint32_t n_tris, uint32_t* n_nodes, uint32_t* max_depth) {
+  if (!tri_pos && n_tris) return RRT_E_INVALID;
+  BvhBuildResult bvh;
+  if (!build_bvh(tri_pos, n_tris, 0, &bvh)) return RRT_E_NOMEM;
+  if (n_nodes) *n_nodes = bvh.n_nodes;
+  if (max_depth) *max_depth = bvh.max_depth;
+  const uint64_t bad = validate_bvh(tri_pos, n_tris, bvh);
+  free_bvh(&bvh);
+  return (int64_t)std::min<uint64_t>(bad, (uint64_t)INT64_MAX);
+}
+
 int rrt_reset_stats(rrt_ctx* ctx) {
   if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
   int rc = bind_device(ctx);

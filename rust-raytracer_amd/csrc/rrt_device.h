@@ -18,19 +18,26 @@ struct uint4 { uint32_t x, y, z, w; };
 
 namespace rrt {
 
-// One 4-wide BVH node, 128 B = two 64-byte fetches: the boxes of up to four children, one
-// component of all four per 16-byte load, and where they lead.  child >= 0: index of an inner
-// node.  child < 0: a leaf of 1..4 triangles of the leaf-ordered triangle arrays,
-// ~child = first << 2 | (count - 1).  An absent child has an inverted box that no ray enters.
-// Four wide rather than two because traversal is bound by the chain of dependent node fetches of
-// each ray, not by arithmetic: half the steps per ray for the same bytes.
-struct alignas(128) BvhNode {
-  float lo_x[4], lo_y[4], lo_z[4];
-  float hi_x[4], hi_y[4], hi_z[4];
+// One 4-wide BVH node, 64 B = four 16-byte loads.  The boxes of up to four children are stored as
+// 8-bit offsets from the node's own corner: plane = origin[k] + q * 2^(exp[k] - 127), rounded outwards
+// by the builder, so a decoded box always contains the exact one (at most 1/255 of the node's extent
+// looser per side).  child >= 0: index of an inner node.  child < 0: a leaf of 1..4 triangles of the
+// leaf-ordered triangle arrays, ~child = first << 2 | (count - 1).  kAbsentChild: no such child.
+// Four wide rather than two: half the steps per ray.  Compressed rather than six floats per child:
+// what bounds traversal is the number of 16-byte loads the lanes of a wave issue to scattered
+// addresses -- the memory pipeline of a CU retires about one such load per lane and clock, whatever
+// the cache level it is served from -- and a node costs four of them instead of seven.
+struct alignas(64) BvhNode {
+  float origin[3];      // minimum corner of the union of the children
+  uint8_t exp[3];       // per axis: biased exponent of the grid step (the exponent field of a float)
+  uint8_t pad0;
   int32_t child[4];
-  int32_t pad[4];
+  uint8_t qlo[3][4];    // [axis][child]: grid steps from origin to the child's minimum (rounded down)
+  uint8_t qhi[3][4];    // ... to its maximum (rounded up)
+  uint32_t pad1[2];
 };
-static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+constexpr int32_t kAbsentChild = INT32_MIN;
 
 // Intersection record of a triangle, 48 B, leaf order: vertex 0 and the two
 // edges Moeller-Trumbore needs.  v0.w carries the scene-order object id.
@@ -133,5 +140,7 @@ struct BvhBuildResult {
 // tri_pos: [n][3][3] floats.  threads = 0: hardware concurrency.  Returns false on allocation failure.
 bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuildResult* out);
 void free_bvh(BvhBuildResult* r);
+// Number of violations of the hierarchy's invariants (0 = sound): see bvh_build.cpp.
+uint64_t validate_bvh(const float* tri_pos, uint32_t n_tris, const BvhBuildResult& b);
 
 }  // namespace rrt

@@ -40,6 +40,9 @@
 
 // Launch bounds of the kernels that traverse: the second figure (waves per SIMD the register
 // allocator has to make room for) trades registers per ray against rays in flight.
+#ifndef RRT_EXTEND_WAVES
+#define RRT_EXTEND_WAVES 5
+#endif
 #ifdef RRT_TRACE_WAVES
 #define RRT_TRACE_BOUNDS __launch_bounds__(rrt::kTraceBlock, RRT_TRACE_WAVES)
 #else
@@ -457,7 +460,7 @@ struct ExtendJob {
 
 // (Bounded to 5 waves per SIMD = 96 registers, which is what it uses: a guard against creeping over.)
 template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock, 5) k_extend(RenderParams p, uint32_t parity) {
+__global__ void __launch_bounds__(kTraceBlock, RRT_EXTEND_WAVES) k_extend(RenderParams p, uint32_t parity) {
   RRT_DECLARE_TRACE_STACK();
   RRT_DECLARE_SHAPES();
   const SceneTables* sc = shapes_to_lds(p.scene, rrt_shape_words);

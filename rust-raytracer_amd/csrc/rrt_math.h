@@ -28,8 +28,11 @@ RRT_DEV V3 operator/(V3 a, float s) {
   const float r = 1.0f / s;
   return V3{a.x * r, a.y * r, a.z * r};
 }
-RRT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-RRT_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// The library is compiled with -ffp-contract=off: the same source then rounds the same way in every
+// kernel it is inlined into (a ray must find the same hit whether k_primary or k_extend traces it),
+// and the fused operations that are wanted are written out.
+RRT_DEV float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+RRT_DEV V3 cross(V3 a, V3 b) { return V3{fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))}; }
 RRT_DEV float norm2(V3 a) { return dot(a, a); }
 RRT_DEV float norm(V3 a) { return sqrtf(dot(a, a)); }
 RRT_DEV V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }

@@ -23,7 +23,7 @@ constexpr int kTraceBlock = 256;   // threads per block of every kernel that tra
 #define RRT_LDS_STACK_DEPTH 12
 #endif
 constexpr int kLdsDepth = RRT_LDS_STACK_DEPTH;
-constexpr int kStackDepth = 192;   // a 4-wide node pushes up to 3 entries: trees up to 63 inner levels (checked at upload)
+constexpr int kStackDepth = 192;   // a node pushes up to 3 entries: trees up to 63 inner levels (checked at upload)
 constexpr int kSpillDepth = kStackDepth - kLdsDepth;
 #define RRT_DECLARE_TRACE_STACK() __shared__ int2 rrt_trace_stack[(rrt::kLdsDepth > 0 ? rrt::kLdsDepth : 1) * rrt::kTraceBlock]
 // The LDS part is addressed through a pointer that names its address space.  Through a generic
@@ -69,21 +69,19 @@ RRT_DEV RayPre prepare_ray(V3 o, V3 d) {
   const float dx = fabsf(d.x) > eps ? d.x : copysignf(eps, d.x);
   const float dy = fabsf(d.y) > eps ? d.y : copysignf(eps, d.y);
   const float dz = fabsf(d.z) > eps ? d.z : copysignf(eps, d.z);
-  r.inv = mk(1.0f / dx, 1.0f / dy, 1.0f / dz);
+  // hardware reciprocals (1 ulp): the slab test below has more slack than that
+  r.inv = mk(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
   r.ood = o * r.inv;
   return r;
 }
 
-// Entry distance of the ray into a box, or +inf when it misses [tmin, tmax].
-RRT_DEV float slab(const RayPre& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float tmin,
-                   float tmax) {
-  const float x0 = fmaf(mnx, r.inv.x, -r.ood.x), x1 = fmaf(mxx, r.inv.x, -r.ood.x);
-  const float y0 = fmaf(mny, r.inv.y, -r.ood.y), y1 = fmaf(mxy, r.inv.y, -r.ood.y);
-  const float z0 = fmaf(mnz, r.inv.z, -r.ood.z), z1 = fmaf(mxz, r.inv.z, -r.ood.z);
+// Entry distance of the ray into a child's box from the distances to its six planes, or +inf when
+// the ray misses the box within [tmin, tmax] or the node has no such child.
+RRT_DEV float child_entry(float x0, float x1, float y0, float y1, float z0, float z1, float tmin, float tmax, int child) {
   const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
   const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
   // widen by a few ulps so that rounding never rejects a box the exact test would enter
-  return tn <= tf * 1.0000005f ? tn : INFINITY;
+  return (tn <= tf * 1.0000005f && child != kAbsentChild) ? tn : INFINITY;
 }
 
 // Moeller-Trumbore on an already loaded record.  Accepts t in (tmin, tmax); barycentrics u
@@ -105,7 +103,7 @@ RRT_DEV bool intersect_tri(const TriRec& rec, const RayPre& r, float tmin, float
   const V3 v0 = mk(rec.v0), e1 = mk(rec.e1), e2 = mk(rec.e2);
   const V3 pvec = cross(r.d, e2);
   const float det = dot(e1, pvec);
-  const float inv_det = 1.0f / det;
+  const float inv_det = __builtin_amdgcn_rcpf(det);  // 1 ulp; a full division is ten instructions per triangle
   const V3 tvec = r.o - v0;
   const float u = dot(tvec, pvec) * inv_det;
   const V3 qvec = cross(tvec, e1);
@@ -183,8 +181,9 @@ struct Ray {
 #define RRT_LEAF_FRACTION 2
 #endif
 
-// One inner-node step of a lane: the four child boxes against the ray, nearest child next, the
-// other children that were hit onto the stack (farthest first, so the nearest comes off first).
+// One inner-node step of a lane: the four child boxes (decoded from the node's 8-bit grid) against
+// the ray, nearest child next, the other children that were hit onto the stack (farthest first, so
+// the nearest comes off first).
 #define RRT_CSWAP(ta, ca, tb, cb)                   \
   do {                                              \
     const bool sw_ = tb < ta;                       \
@@ -195,15 +194,32 @@ struct Ray {
     tb = tt_;                                       \
     cb = cc_;                                       \
   } while (0)
-#define RRT_NODE_STEP(lx, ly, lz, hx, hy, hz, ch)                                        \
+// The node's four 16-byte words: {origin, exponents}, children, {lo x, lo y, lo z, hi x}, {hi y, hi z}.
+#define RRT_NODE_LOAD(np, w0, w1, w2, w3)                                                \
+  do {                                                                                   \
+    w0 = (np)[0]; w1 = (np)[1]; w2 = (np)[2]; w3 = (np)[3];                              \
+  } while (0)
+// Distance along the ray to plane q of an axis: (origin + q * step - o) / d = q * (step / d) + (origin - o) / d.
+#define RRT_Q(w, i) ((float)(((w) >> (8 * (i))) & 0xffu))
+#define RRT_CHILD_T(i, c)                                                                \
+  child_entry(fmaf(RRT_Q(w2.x, i), ax, bx), fmaf(RRT_Q(w2.w, i), ax, bx),                \
+              fmaf(RRT_Q(w2.y, i), ay, by), fmaf(RRT_Q(w3.x, i), ay, by),                \
+              fmaf(RRT_Q(w2.z, i), az, bz), fmaf(RRT_Q(w3.y, i), az, bz), tmin, tmax, c)
+#define RRT_NODE_STEP(w0, w1, w2, w3)                                                    \
   do {                                                                                   \
     RRT_DBG_STEP();                                                                      \
     if (COUNT) ctr->nodes++;                                                             \
-    float t0 = slab(r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, tmin, tmax);                  \
-    float t1 = slab(r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, tmin, tmax);                  \
-    float t2 = slab(r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, tmin, tmax);                  \
-    float t3 = slab(r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, tmin, tmax);                  \
-    int c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;                                      \
+    const float ax = __uint_as_float((w0.w & 0xffu) << 23) * r.inv.x;                    \
+    const float ay = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * r.inv.y;             \
+    const float az = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * r.inv.z;            \
+    const float bx = fmaf(__uint_as_float(w0.x), r.inv.x, -r.ood.x);                     \
+    const float by = fmaf(__uint_as_float(w0.y), r.inv.y, -r.ood.y);                     \
+    const float bz = fmaf(__uint_as_float(w0.z), r.inv.z, -r.ood.z);                     \
+    int c0 = (int)w1.x, c1 = (int)w1.y, c2 = (int)w1.z, c3 = (int)w1.w;                  \
+    float t0 = RRT_CHILD_T(0, c0);                                                       \
+    float t1 = RRT_CHILD_T(1, c1);                                                       \
+    float t2 = RRT_CHILD_T(2, c2);                                                       \
+    float t3 = RRT_CHILD_T(3, c3);                                                       \
     /* sort the four by entry distance (misses are +inf and end up last) */              \
     RRT_CSWAP(t0, c0, t1, c1);                                                           \
     RRT_CSWAP(t2, c2, t3, c3);                                                           \
@@ -392,17 +408,14 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
       for (;;) {
         const bool at_node = state == kTravelling && cur >= 0;
         const bool at_leaf = state == kTravelling && cur < 0;
-        float4 lx, ly, lz, hx, hy, hz;
-        int4 ch;
+        uint4 w0, w1, w2, w3;
         TriRec rec;
         int ti = 0;
-        lx = ly = lz = hx = hy = hz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        ch = make_int4(0, 0, 0, 0);
-        rec.v0 = rec.e1 = rec.e2 = lx;
+        w0 = w1 = w2 = w3 = make_uint4(0u, 0u, 0u, 0u);
+        rec.v0 = rec.e1 = rec.e2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (at_node) {
-          const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-          lx = np[0]; ly = np[1]; lz = np[2]; hx = np[3]; hy = np[4]; hz = np[5];
-          ch = reinterpret_cast<const int4*>(np)[6];
+          const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
+          RRT_NODE_LOAD(np, w0, w1, w2, w3);
         }
         if (at_leaf) {
           ti = (~cur) >> 2;  // leaf: ~cur = first << 2 | (count - 1)
@@ -413,7 +426,7 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
         asm volatile("" ::: "memory");
         RRT_DBG_ADD(3, 1);
         if (at_node) {
-          RRT_NODE_STEP(lx, ly, lz, hx, hy, hz, ch);
+          RRT_NODE_STEP(w0, w1, w2, w3);
         }
         if (at_leaf) {
           if (COUNT) ctr->tris++;
@@ -442,10 +455,10 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
         for (;;) {
           RRT_DBG_ADD(5, __popcll(__ballot(state == kTravelling && cur >= 0)));
           if (state == kTravelling && cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-            const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
-            const int4 ch = reinterpret_cast<const int4*>(np)[6];
-            RRT_NODE_STEP(lx, ly, lz, hx, hy, hz, ch);
+            const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
+            uint4 w0, w1, w2, w3;
+            RRT_NODE_LOAD(np, w0, w1, w2, w3);
+            RRT_NODE_STEP(w0, w1, w2, w3);
           }
           const unsigned long long inner = __ballot(state == kTravelling && cur >= 0);
           const unsigned long long at_leaf = __ballot(state == kTravelling && cur < 0);
@@ -503,7 +516,9 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
 // through: f32 slab test on the box {pos, pos + a + b} (objects/rectangle.rs:136-146).
 RRT_DEV bool rect_box_pass(const DeviceRect& q, const RayPre& r, int mode) {
   if (mode == RRT_RECT_AABB_OFF) return true;
-  const float inv[3] = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+  // the ray's reciprocals; a component that is exactly zero divides to an infinity of its sign as in the original
+  const float inv[3] = {r.d.x == 0.0f ? copysignf(INFINITY, r.d.x) : r.inv.x, r.d.y == 0.0f ? copysignf(INFINITY, r.d.y) : r.inv.y,
+                        r.d.z == 0.0f ? copysignf(INFINITY, r.d.z) : r.inv.z};
   const float o[3] = {r.o.x, r.o.y, r.o.z};
   float tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
@@ -521,7 +536,7 @@ RRT_DEV bool intersect_rect(const DeviceRect& q, const RayPre& r, float* t_out) 
   const V3 n = mk(q.normal);
   const float denom = dot(n, r.d);
   if (fabsf(denom) < 1e-9f) return false;
-  const float t = dot(mk(q.pos) - r.o, n) / denom;
+  const float t = dot(mk(q.pos) - r.o, n) * __builtin_amdgcn_rcpf(denom);
   if (t < 1e-9f) return false;
   const V3 p0p = r.o + r.d * t - mk(q.pos);
   const float a = dot(p0p, mk(q.a)) * q.inv_aa;
@@ -536,7 +551,7 @@ RRT_DEV bool intersect_plane(const DevicePlane& pl, const RayPre& r, float* t_ou
   const V3 n = mk(pl.normal);
   const float denom = dot(n, r.d);
   if (fabsf(denom) < 1e-9f) return false;
-  const float t = dot(mk(pl.pos) - r.o, n) / denom;
+  const float t = dot(mk(pl.pos) - r.o, n) * __builtin_amdgcn_rcpf(denom);
   if (t < 0.0000001f) return false;
   *t_out = t;
   return true;
@@ -545,8 +560,11 @@ RRT_DEV bool intersect_plane(const DevicePlane& pl, const RayPre& r, float* t_ou
 // objects/sphere.rs:116-154
 RRT_DEV bool intersect_sphere(const DeviceSphere& s, const RayPre& r, float* t_out) {
   const V3 oc = r.o - mk(s.center);
-  const float a = dot(r.d, r.d), b = dot(oc, r.d), c = dot(oc, oc) - s.radius * s.radius;
-  const float disc = b * b - a * c;
+  const float a = dot(r.d, r.d), b = dot(oc, r.d);
+  // discriminant b^2 - a c = a (radius^2 - |l|^2), l = the part of oc across the ray: in f32 the textbook
+  // form loses a grazing hit's digits in the difference of two large squares, this one does not
+  const V3 l = oc - r.d * (b / a);
+  const float disc = a * fmaf(s.radius, s.radius, -dot(l, l));
   if (disc < 0.0f) return false;
   const float sq = sqrtf(disc);
   float t = (-b - sq) / a;
@@ -567,8 +585,9 @@ RRT_DEV bool intersect_others(const SceneTables* __restrict__ sc, const RayPre& 
   int code = sc->n_tris;
   for (int i = 0; i < sc->n_rects; ++i, ++code) {
     float t;
-    if (code != skip_a && code != skip_b && rect_box_pass(sc->rects[i], r, sc->rect_aabb_mode) && intersect_rect(sc->rects[i], r, &t) &&
-        t < tmax) {
+    // the quad itself first: few rays pass it, and only those need the box test
+    if (code != skip_a && code != skip_b && intersect_rect(sc->rects[i], r, &t) && t < tmax &&
+        rect_box_pass(sc->rects[i], r, sc->rect_aabb_mode)) {
       if (ANY) return true;
       tmax = t; hit->prim = code; hit->t = t; hit->u = 0.0f; hit->v = 0.0f; found = true;
     }

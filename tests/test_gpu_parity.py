@@ -39,6 +39,8 @@ def _check_first_hit(ctx, rays, ref_prim, ref_t, margin):
         rel.max(), np.quantile(rel, 0.999), err.max(), (rel > 1e-5).sum(),
         ref_t[hit][rel > 1e-5].min() if (rel > 1e-5).any() else 0.0))
     scale = np.maximum(ref_t[hit], np.abs(np.asarray(rays)[hit, :3]).max(axis=1))
+    worst = np.argmax(err / scale)
+    print("worst ray: object %d, t %.6g, error %.3g" % (ref_prim[hit][worst], ref_t[hit][worst], err[worst]))
     assert (err <= 1e-5 * scale).all(), (err / scale).max()
     if (~clear).any():
         print("set aside: %d rays, agreement on them %.3f" % ((~clear).sum(), (dev_prim[~clear] == ref_prim[~clear]).mean()))

@@ -67,6 +67,27 @@ def test_without_a_gpu_the_product_fails_loudly(rrt):
 
 
 # --------------------------------------------------------------------------- loader
+def test_hierarchy_invariants(rrt):
+    """The 4-wide hierarchy with 8-bit quantised child boxes, built on the host as rrt_upload_scene
+    builds it: every triangle inside the decoded box of every node above it, each in exactly one leaf.
+    Random soup, a regular grid (planes exactly on grid steps: boxes with zero padding), flat and
+    degenerate triangles, huge and tiny coordinates side by side, 0 / 1 / 5 triangles."""
+    rng = np.random.default_rng(5)
+    soup = rng.uniform(-1, 1, (20000, 1, 3)) * 50 + rng.normal(0, 0.3, (20000, 3, 3))
+    g = np.stack(np.meshgrid(np.arange(40.0), np.arange(40.0), indexing="ij"), axis=-1).reshape(-1, 2)
+    grid = np.zeros((len(g), 3, 3))
+    grid[:, 0, :2], grid[:, 1, :2], grid[:, 2, :2] = g, g + [1, 0], g + [0, 1]   # all in the plane z = 0
+    mixed = np.concatenate([soup[:3000] * 1e-4 + 1000.0, soup[:3000] * 1e3, np.zeros((10, 3, 3)),
+                            np.tile(soup[:1], (20, 1, 1))])                       # duplicates and points
+    for name, tris in (("soup", soup), ("grid", grid), ("mixed", mixed), ("one", soup[:1]), ("five", soup[:5]),
+                       ("none", soup[:0])):
+        bad, n_nodes, depth = rrt.bvh_selfcheck(tris)
+        assert bad == 0, (name, bad)
+        assert n_nodes >= 1 and depth >= 1
+        if len(tris) > 100:
+            assert n_nodes < len(tris) and depth < 64, (name, n_nodes, depth)
+
+
 def test_cornell_scene(rrt, cornell):
     scene, rs = cornell
     d = scene.desc()
