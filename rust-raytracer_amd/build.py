@@ -29,6 +29,13 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# Floating point: no contraction the source does not spell out (the same ray must round the same way in
+# every kernel that traces it; the fused operations that matter are written as fmaf), and hardware
+# reciprocal / square root (1 ulp) instead of the correctly rounded sequences, which were a fifth of
+# the shading kernel's instructions.
+HIP_FP_FLAGS = ["-ffp-contract=off", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+
+
 def _run(cmd, cwd):
     print("+", " ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=cwd)
@@ -39,7 +46,7 @@ def build_hip(force=False, extra_flags=()):
     deps = [os.path.join(CSRC, f) for f in HIP_SOURCES + HIP_HEADERS] + [os.path.join(ROOT, "include", "rrt.h")]
     if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-pthread", *extra_flags,
+        _run([hipcc, "--offload-arch=gfx950", "-O3", *HIP_FP_FLAGS, "-std=c++17", "-fPIC", "-shared", "-pthread", *extra_flags,
               "-o", out, *HIP_SOURCES, "-ldl"], CSRC)
     return out
 

@@ -24,7 +24,10 @@ namespace {
 thread_local std::string g_create_error;
 
 constexpr uint32_t kSlotLimit = 1u << 30;          // slot numbers share a word with two flag bits
-constexpr double kAutoMemoryShare = 0.6;           // automatic pool size: this share of the free device memory
+#ifndef RRT_AUTO_MEMORY_SHARE
+#define RRT_AUTO_MEMORY_SHARE 0.6
+#endif
+constexpr double kAutoMemoryShare = RRT_AUTO_MEMORY_SHARE;  // automatic pool size: this share of the free device memory
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxSlotsPerPixel = 1024;
 constexpr uint32_t kQueueGridBlocks = 8192;  // 32 blocks per CU for the kernels that walk a queue chunk by chunk
@@ -70,6 +73,7 @@ struct rrt_ctx {
   std::vector<void*> state_allocs;
   uint32_t state_slots = 0, state_depth = 0;
   bool state_has_mis = false;
+  bool state_regenerates = false;  // the state has what regenerating slots need (accum, camera-ray queue)
 
   // reconstruction filter
   uint32_t filter_method = RRT_FILTER_NONE;
@@ -154,28 +158,30 @@ int state_alloc(rrt_ctx* ctx, T** out, size_t count) {
 }
 
 // Device memory ensure_state takes for n_slots slots (0 for none).
-uint64_t state_bytes(uint32_t n_slots, bool with_mis) {
+// `regenerates`: slots work through several samples (or splat through a filter), which takes the sum
+// of finished paths and the camera-ray queue besides.
+uint64_t state_bytes(uint32_t n_slots, bool with_mis, bool regenerates) {
   if (n_slots == 0) return 0;
   const uint64_t n = n_slots;
   const uint64_t seg_cap = 2 * ((n + kSegments - 1) / kSegments) + n / 2048 + 4096;
   const uint64_t ray_seg_cap = (n + kSegments - 1) / kSegments + 1024;
-  return n * (16ull * (with_mis ? 12 : 9) + 4) + 4ull * seg_cap * kSegments * 4 + 3ull * ray_seg_cap * kSegments * 32;
+  return n * (64ull * (with_mis ? 3 : 2) + (regenerates ? 2 : 1) * 16 + 4) + 4ull * seg_cap * kSegments * 4 +
+         (regenerates ? 3ull : 2ull) * ray_seg_cap * kSegments * 32;
 }
 
 // Path state for n_slots paths and `depth` bounces; grows only.
-int ensure_state(rrt_ctx* ctx, uint32_t n_slots, uint32_t depth, bool need_mis) {
-  if (ctx->state_slots >= n_slots && ctx->state_depth >= depth && (ctx->state_has_mis || !need_mis)) return RRT_OK;
+int ensure_state(rrt_ctx* ctx, uint32_t n_slots, uint32_t depth, bool need_mis, bool regenerates) {
+  if (ctx->state_slots >= n_slots && ctx->state_depth >= depth && (ctx->state_has_mis || !need_mis) &&
+      (ctx->state_regenerates || !regenerates))
+    return RRT_OK;
   free_state(ctx);
   PathArrays& a = ctx->arrays;
   int rc;
-  float4** main_arrays[] = {&a.ray_o, &a.ray_d, &a.beta, &a.radiance, &a.accum, &a.hit, &a.sh_o, &a.sh_d, &a.sh_c};
-  for (float4** arr : main_arrays)
-    if ((rc = state_alloc(ctx, arr, n_slots)) != RRT_OK) return rc;
-  if (need_mis) {
-    float4** mis_arrays[] = {&a.mis_o, &a.mis_d, &a.mis_c};
-    for (float4** arr : mis_arrays)
-      if ((rc = state_alloc(ctx, arr, n_slots)) != RRT_OK) return rc;
-  }
+  if ((rc = state_alloc(ctx, &a.trace, n_slots)) != RRT_OK) return rc;
+  if ((rc = state_alloc(ctx, &a.shadow, n_slots)) != RRT_OK) return rc;
+  if (need_mis && (rc = state_alloc(ctx, &a.mis, n_slots)) != RRT_OK) return rc;
+  if ((rc = state_alloc(ctx, &a.radiance, n_slots)) != RRT_OK) return rc;
+  if (regenerates && (rc = state_alloc(ctx, &a.accum, n_slots)) != RRT_OK) return rc;
   // queues: kSegments fixed-size segments.  A segment takes what the chunks c = segment (mod
   // kSegments) of a launch produce; the start queue is fed by two launches (extend and shade).
   // (extend hands in results per index block of at most 1024 jobs, shade per chunk of 256.)
@@ -188,7 +194,7 @@ int ensure_state(rrt_ctx* ctx, uint32_t n_slots, uint32_t depth, bool need_mis) 
   a.ray_seg_cap = (n_slots + kSegments - 1) / kSegments + 1024;
   float4** ray_queues[] = {&a.rays_cont[0], &a.rays_cont[1], &a.rays_camera};
   for (float4** q : ray_queues)
-    if ((rc = state_alloc(ctx, q, (size_t)a.ray_seg_cap * kSegments * 2)) != RRT_OK) return rc;
+    if ((regenerates || q != &a.rays_camera) && (rc = state_alloc(ctx, q, (size_t)a.ray_seg_cap * kSegments * 2)) != RRT_OK) return rc;
   if ((rc = state_alloc(ctx, &a.sample, n_slots)) != RRT_OK) return rc;
   if ((rc = state_alloc(ctx, &a.counters, (size_t)kCounterRows * kSegments * kCounterStride)) != RRT_OK) return rc;
   if (!ctx->h_pending)
@@ -196,6 +202,7 @@ int ensure_state(rrt_ctx* ctx, uint32_t n_slots, uint32_t depth, bool need_mis) 
   ctx->state_slots = n_slots;
   ctx->state_depth = depth;
   ctx->state_has_mis = need_mis;
+  ctx->state_regenerates = regenerates;
   return RRT_OK;
 }
 
@@ -770,30 +777,39 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
   // a wave together (one pixel, one bounce).  Measured at 1080p, 256 spp: 1.6 G samples/s with 16
   // slots per pixel, 2.4 G with 64, 3.2 G with 256.
   const bool need_mis = ctx->h_scene.has_env != 0;
-  uint64_t max_slots = ctx->max_slots;
-  if (max_slots == 0) {
-    size_t free_bytes = 0, total_bytes = 0;
-    HIP_TRY(ctx, hipMemGetInfo(&free_bytes, &total_bytes));
-    const double have = (double)free_bytes + (double)state_bytes(ctx->state_slots, ctx->state_has_mis);
-    max_slots = (uint64_t)(have * kAutoMemoryShare / (double)state_bytes(1u << 20, need_mis) * (double)(1u << 20));
-    max_slots = std::min<uint64_t>(std::max<uint64_t>(max_slots, 1u << 16), kSlotLimit);
-  }
-  uint32_t k, tiles_per_pass;
-  for (;;) {
-    k = ctx->batch_samples ? ctx->batch_samples
-                           : (uint32_t)std::min<uint64_t>(kMaxSlotsPerPixel, std::max<uint64_t>(1, max_slots / (total_tiles * 64)));
-    k = std::min(k, n_samples);
-    tiles_per_pass = (uint32_t)std::min<uint64_t>(total_tiles, std::max<uint64_t>(1, max_slots / (64ull * k)));
-    rc = ensure_state(ctx, tiles_per_pass * 64 * k, s->depth_limit, need_mis);
-    // an automatic size that the allocator cannot deliver after all (fragmentation, another
-    // process on the device): try again with half
-    if (rc == RRT_E_NOMEM && ctx->max_slots == 0 && max_slots > (1u << 16)) {
-      free_state(ctx);
-      max_slots /= 2;
-      continue;
+  // One sample per slot (nothing regenerates) needs less state per slot: sized for that first, and
+  // for regenerating slots if the samples then do not all fit.
+  const bool filtered = ctx->filter_method != RRT_FILTER_NONE;
+  uint32_t k = 0, tiles_per_pass = 0;
+  for (int attempt = filtered ? 1 : 0; attempt < 2; ++attempt) {
+    const bool regenerates = attempt == 1;
+    uint64_t max_slots = ctx->max_slots;
+    if (max_slots == 0) {
+      size_t free_bytes = 0, total_bytes = 0;
+      HIP_TRY(ctx, hipMemGetInfo(&free_bytes, &total_bytes));
+      const double have = (double)free_bytes + (double)state_bytes(ctx->state_slots, ctx->state_has_mis, ctx->state_regenerates);
+      max_slots = (uint64_t)(have * kAutoMemoryShare / (double)state_bytes(1u << 20, need_mis, regenerates) * (double)(1u << 20));
+      max_slots = std::min<uint64_t>(std::max<uint64_t>(max_slots, 1u << 16), kSlotLimit);
     }
-    if (rc != RRT_OK) return rc;
-    break;
+    bool fits = true;
+    for (;;) {
+      k = ctx->batch_samples ? ctx->batch_samples
+                             : (uint32_t)std::min<uint64_t>(kMaxSlotsPerPixel, std::max<uint64_t>(1, max_slots / (total_tiles * 64)));
+      k = std::min(k, n_samples);
+      if (!regenerates && k < n_samples) { fits = false; break; }
+      tiles_per_pass = (uint32_t)std::min<uint64_t>(total_tiles, std::max<uint64_t>(1, max_slots / (64ull * k)));
+      rc = ensure_state(ctx, tiles_per_pass * 64 * k, s->depth_limit, need_mis, regenerates);
+      // an automatic size that the allocator cannot deliver after all (fragmentation, another
+      // process on the device): try again with half
+      if (rc == RRT_E_NOMEM && ctx->max_slots == 0 && max_slots > (1u << 16)) {
+        free_state(ctx);
+        max_slots /= 2;
+        continue;
+      }
+      if (rc != RRT_OK) return rc;
+      break;
+    }
+    if (fits) break;
   }
 
   RenderParams p;

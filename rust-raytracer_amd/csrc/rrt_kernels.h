@@ -86,20 +86,32 @@ enum : uint32_t {
 RRT_DEV uint32_t row_start(uint32_t parity) { return parity ? kRowStart1 : kRowStart0; }
 RRT_DEV uint32_t row_cont(uint32_t parity) { return parity ? kRowCont1 : kRowCont0; }
 
+// Per-slot state that one kernel touches together sits in one 64-byte record: the slots a launch
+// works on are scattered over the pool, and with one array per field every 16-byte field was a
+// memory transaction of its own (shade moved ~1 KB per event for ~350 B of payload).
+struct alignas(64) TraceRecord {
+  float4 ray_o;  // xyz origin of the ray that produced `hit` (written by extend when the ray hits)
+  float4 ray_d;  // xyz direction of the slot's last ray, w = bounce << 1 | previous bounce sampled a specular lobe
+  float4 hit;    // prim (int bits), t, u, v
+  float4 beta;   // path throughput (`contribution` in the reference); 1 at bounce 0 and not stored
+};
+struct alignas(64) ShadowRecord {
+  float4 sh_o;   // light-sample visibility ray: origin xyz, w = max distance
+  float4 sh_d;   // direction xyz, w = object code of the sampled light's quad (int bits)
+  float4 sh_c;   // contribution rgb, w = flag bits | object the rays leave << 3
+  float4 pad;
+};
+struct alignas(64) MisRecord {
+  float4 mis_o, mis_d, mis_c, pad;
+};
+
 struct PathArrays {
-  float4* ray_o;      // xyz origin of the ray that produced `hit` (written by extend when the ray hits)
-  float4* ray_d;      // xyz direction of the slot's last ray, w = bounce << 1 | previous bounce sampled a specular lobe
+  TraceRecord* trace;    // per slot: the ray being traced, what it hit, the path's throughput
+  ShadowRecord* shadow;  // per slot: the light-sample visibility ray shade hands to connect
+  MisRecord* mis;        // per slot: escape ray of the BSDF-sampling estimator (environment light only)
   uint32_t* sample;   // sample index of the slot's current path
-  float4* beta;       // path throughput (`contribution` in the reference); 1 at bounce 0 and not stored
   float4* radiance;   // L of the current path; written by shade at bounce 0
   float4* accum;      // sum of the slot's finished paths, w = their number
-  float4* hit;        // prim (int bits), t, u, v
-  float4* sh_o;       // light-sample visibility ray: origin xyz, w = max distance
-  float4* sh_d;       // direction xyz, w = object code of the sampled light's quad (int bits)
-  float4* sh_c;       // contribution rgb, w = flag bits | object the rays leave << 3
-  float4* mis_o;      // escape ray of the BSDF-sampling estimator (environment light only)
-  float4* mis_d;
-  float4* mis_c;
   uint32_t* q_start[2];  // slots whose path has ended (or not begun), with entry flags
   // Ray queues carry the rays themselves, two float4 per entry: (origin, slot bits), (direction,
   // state bits as in ray_d).  A traversing lane that takes a new job then needs one memory round
@@ -329,16 +341,16 @@ __global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam,
       if (p.single) {
         // only rays that escaped after a specular bounce come here (src/tracer.rs:44-63): they
         // still owe the environment; nothing is banked and no slot starts a second path
-        const float4 d = p.a.ray_d[slot];
+        const float4 d = p.a.trace[slot].ray_d;
         const V3 le = escape_radiance(p.scene, p.env, mk(d));
-        const float4 b = p.a.beta[slot];
+        const float4 b = p.a.trace[slot].beta;
         float4 l4 = p.a.radiance[slot];
         l4.x += b.x * le.x; l4.y += b.y * le.y; l4.z += b.z * le.z;
         p.a.radiance[slot] = l4;
       } else {
         float4 l4;
         if (entry & kEscaped) {
-          const float4 d = p.a.ray_d[slot];
+          const float4 d = p.a.trace[slot].ray_d;
           const uint32_t state = __float_as_uint(d.w);
           if (state == 0u) {
             // a camera ray that escapes sees the lights' environment term (src/tracer.rs:50-53)
@@ -347,7 +359,7 @@ __global__ void __launch_bounds__(256) k_start(RenderParams p, CameraParams cam,
             l4 = p.a.radiance[slot];
             if (state & 1u) {  // later rays only after a specular bounce (src/tracer.rs:44-63)
               const V3 le = escape_radiance(p.scene, p.env, mk(d));
-              const float4 b = p.a.beta[slot];
+              const float4 b = p.a.trace[slot].beta;
               l4.x += b.x * le.x; l4.y += b.y * le.y; l4.z += b.z * le.z;
             }
           }
@@ -427,10 +439,10 @@ struct ExtendJob {
     if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
     hit_surface = h.prim >= 0;
     // shade needs the whole ray, start (for a ray that escaped) its direction and state
-    p.a.ray_d[slot] = f4(r.d, __uint_as_float(state));
+    p.a.trace[slot].ray_d = f4(r.d, __uint_as_float(state));
     if (hit_surface) {
-      p.a.ray_o[slot] = f4(r.o, 0.0f);
-      p.a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+      p.a.trace[slot].ray_o = f4(r.o, 0.0f);
+      p.a.trace[slot].hit = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
     }
     return false;
   }
@@ -517,9 +529,9 @@ struct PrimaryJob {
     Hit h = tri_hit;
     if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
     if (h.prim >= 0) {
-      p.a.ray_o[slot] = f4(r.o, 0.0f);
-      p.a.ray_d[slot] = f4(r.d, __uint_as_float(0u));
-      p.a.hit[slot] = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
+      p.a.trace[slot].ray_o = f4(r.o, 0.0f);
+      p.a.trace[slot].ray_d = f4(r.d, __uint_as_float(0u));
+      p.a.trace[slot].hit = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
       kind = 1;
     } else if (single) {
       // a camera ray that escapes sees the lights' environment term (src/tracer.rs:50-53): the
@@ -527,7 +539,7 @@ struct PrimaryJob {
       p.a.radiance[slot] = f4(escape_radiance(p.scene, p.env, r.d), 0.0f);
       kind = 0;
     } else {
-      p.a.ray_d[slot] = f4(r.d, __uint_as_float(0u));
+      p.a.trace[slot].ray_d = f4(r.d, __uint_as_float(0u));
       kind = 2;
     }
     return false;
@@ -586,11 +598,11 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
   if (i < n) {
     active = true;
     slot = entries[i];
-    const float4 o4 = p.a.ray_o[slot], d4 = p.a.ray_d[slot], h4 = p.a.hit[slot];
+    const float4 o4 = p.a.trace[slot].ray_o, d4 = p.a.trace[slot].ray_d, h4 = p.a.trace[slot].hit;
     const V3 org = mk(o4), dir = mk(d4);
     const uint32_t sample = p.a.sample[slot], bounce = __float_as_uint(d4.w) >> 1;
     V3 beta = mk(1.0f, 1.0f, 1.0f);
-    if (bounce > 0) beta = mk(p.a.beta[slot]);
+    if (bounce > 0) beta = mk(p.a.trace[slot].beta);
     else p.a.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int prim = __float_as_int(h4.x);
     const SceneTables* sc = p.scene;
@@ -622,8 +634,8 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
           // sample, stopping just short of it.  The 1e-9 / 1e-7 margins of the f64 original do not
           // exist in f32: the surface being left and the light's own quad are excluded by identity.
           const float tmax = ls.dist < INFINITY ? ls.dist * (1.0f - 1e-5f) : INFINITY;
-          p.a.sh_o[slot] = f4(s.p, tmax);
-          p.a.sh_d[slot] = f4(ls.wi, __int_as_float(ls.skip));
+          p.a.shadow[slot].sh_o = f4(s.p, tmax);
+          p.a.shadow[slot].sh_d = f4(ls.wi, __int_as_float(ls.skip));
           flags |= kHasLightRay;
           has_light = true;
         }
@@ -640,9 +652,9 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
           const V3 le = env_lookup(sc, p.env, normalize(bs.wi));
           if (!is_zero(le)) {
             const V3 c = beta * f * le * (w * n_lights / bs.pdf);
-            p.a.mis_o[slot] = f4(offset_ray_origin(s.p, s.ng, bs.wi), 0.0f);
-            p.a.mis_d[slot] = f4(bs.wi, 0.0f);
-            p.a.mis_c[slot] = f4(c, 0.0f);
+            p.a.mis[slot].mis_o = f4(offset_ray_origin(s.p, s.ng, bs.wi), 0.0f);
+            p.a.mis[slot].mis_d = f4(bs.wi, 0.0f);
+            p.a.mis[slot].mis_c = f4(c, 0.0f);
             flags |= kHasMisRay;
             has_mis = true;
           }
@@ -666,14 +678,14 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
         next_o = offset_ray_origin(s.p, s.ng, bs.wi);
         next_d = bs.wi;
         next_state = ((bounce + 1) << 1) | (bs.specular ? 1u : 0u);
-        p.a.beta[slot] = f4(beta, 0.0f);
+        p.a.trace[slot].beta = f4(beta, 0.0f);
       }
     }
     has_work = (flags & (kHasLightRay | kHasMisRay)) != 0;
     // without pending light the running sum is unchanged since its last clamp: nothing to do
     // the record carries the object the rays leave: connect must not read hit[], which the next
     // extend may already be overwriting for this slot
-    if (has_work) p.a.sh_c[slot] = f4(light_c, __uint_as_float(flags | ((uint32_t)prim << 3)));
+    if (has_work) p.a.shadow[slot].sh_c = f4(light_c, __uint_as_float(flags | ((uint32_t)prim << 3)));
   }
   ray_queue_push(p, p.a.rays_cont[next], row_cont(next), chunk, survive, slot, next_o, next_d, next_state);
   queue_push(p, p.a.q_start[next], row_start(next), chunk, active && !survive && !p.single, slot);
@@ -711,7 +723,7 @@ struct ConnectJob {
       return true;
     }
     if (stage <= 1 && (flags & kHasMisRay)) {
-      const float4 o = p.a.mis_o[slot], d = p.a.mis_d[slot];
+      const float4 o = p.a.mis[slot].mis_o, d = p.a.mis[slot].mis_d;
       own = light_quad = -1;
       far = INFINITY;
       ray->o = mk(o);
@@ -736,9 +748,9 @@ struct ConnectJob {
   RRT_DEV bool begin(uint32_t i, Ray* ray) {
     slot = entries[i];
     // everything the light-sample ray needs in one round trip, whether or not the entry has one
-    c4 = p.a.sh_c[slot];
+    c4 = p.a.shadow[slot].sh_c;
     l4 = p.a.radiance[slot];
-    const float4 o = p.a.sh_o[slot], d = p.a.sh_d[slot];
+    const float4 o = p.a.shadow[slot].sh_o, d = p.a.shadow[slot].sh_d;
     flags = __float_as_uint(c4.w) & 7u;
     own = (int)(__float_as_uint(c4.w) >> 3);
     light_quad = __float_as_int(d.w);
@@ -758,7 +770,7 @@ struct ConnectJob {
       // (not `stage == 1 ? c4 : mis_c[slot]`: a conditional between two lvalues selects between their
       // addresses, which takes the address of a member and sends the whole job to scratch memory)
       float4 c = c4;
-      if (stage != 1) c = p.a.mis_c[slot];
+      if (stage != 1) c = p.a.mis[slot].mis_c;
       l4.x += c.x; l4.y += c.y; l4.z += c.z;
     }
     return next_ray(ray);
