@@ -31,7 +31,10 @@ constexpr double kAutoMemoryShare = RRT_AUTO_MEMORY_SHARE;  // automatic pool si
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxSlotsPerPixel = 1024;
 constexpr uint32_t kQueueGridBlocks = 8192;  // 32 blocks per CU for the kernels that walk a queue chunk by chunk
-constexpr uint32_t kTraceGridBlocks = 2048;  // 8 blocks = 32 waves per CU: at least what a CU can hold of the traversal kernels
+#ifndef RRT_TRACE_GRID
+#define RRT_TRACE_GRID 2048
+#endif
+constexpr uint32_t kTraceGridBlocks = RRT_TRACE_GRID;  // 8 blocks = 32 waves per CU: at least what a CU can hold of the traversal kernels
 
 inline uint32_t grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 

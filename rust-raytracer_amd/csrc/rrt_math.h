@@ -59,6 +59,13 @@ RRT_DEV V3 offset_ray_origin(V3 p, V3 n, V3 w) {
 RRT_DEV float power_heuristic(float f, float g) { return (f * f) / (f * f + g * g); }
 
 // helpers.rs:200-220 with the two RNG draws passed in
+// Hardware sine and cosine (v_sin_f32 / v_cos_f32, absolute error about 1e-6): every angle in this
+// library is a few turns at most, and the library versions are a hundred instructions apiece.
+RRT_DEV void sincos_fast(float x, float* s, float* c) {
+  *s = __sinf(x);
+  *c = __cosf(x);
+}
+
 RRT_DEV void concentric_sample_disk(float u0, float u1, float* dx, float* dy) {
   const float ox = u0 * 2.0f - 1.0f, oy = u1 * 2.0f - 1.0f;
   if (ox == 0.0f && oy == 0.0f) { *dx = 0.0f; *dy = 0.0f; return; }
@@ -66,7 +73,7 @@ RRT_DEV void concentric_sample_disk(float u0, float u1, float* dx, float* dy) {
   if (fabsf(ox) > fabsf(oy)) { r = ox; theta = kPiOver4 * (oy / ox); }
   else { r = oy; theta = kPiOver2 - kPiOver4 * (ox / oy); }
   float s, c;
-  sincosf(theta, &s, &c);
+  sincos_fast(theta, &s, &c);
   *dx = r * c;
   *dy = r * s;
 }

@@ -125,9 +125,9 @@ RRT_DEV Surface surface_other(const SceneTables* __restrict__ sc, int prim, floa
   float phi = atan2f(op.y, op.x);
   if (phi < 0.0f) phi += 2.0f * kPi;
   const float cos_t = clampf(op.z / sp.radius, -1.0f, 1.0f);
-  const float sin_t = sinf(acosf(cos_t));
+  const float sin_t = sqrtf(fmaxf(1.0f - cos_t * cos_t, 0.0f));  // sin(acos(cos_t))
   float sin_p, cos_p;
-  sincosf(phi, &sin_p, &cos_p);
+  sincos_fast(phi, &sin_p, &cos_p);
   const V3 dp_du = mk(-2.0f * kPi * sp.radius * sin_t * sin_p, 2.0f * kPi * sp.radius * sin_t * cos_p, 0.0f);
   V3 ss = normalize(dp_du);
   V3 ts = cross(n, ss);
@@ -194,7 +194,7 @@ RRT_DEV void ggx_sample_11(float cos_theta, float u1, float u2, float* sx, float
   if (cos_theta > 0.9999f) {
     const float r = sqrtf(u1 / (1.0f - u1));
     float s, c;
-    sincosf(2.0f * kPi * u2, &s, &c);
+    sincos_fast(2.0f * kPi * u2, &s, &c);
     *sx = r * c;
     *sy = r * s;
     return;
@@ -286,7 +286,7 @@ RRT_DEV float microfacet_pdf(const DeviceMaterial& m, V3 wo, V3 wi) {
 RRT_DEV float shift_cos_in(float cos_in) {
   cos_in = fminf(cos_in, 1.0f);
   if (!(cos_in > 0.0f)) return 0.0f;  // the reference yields -0 (or NaN at exactly 0) here: no contribution
-  return fmaxf(cosf(acosf(cos_in) * 1.002f), 0.0f) / cos_in;
+  return fmaxf(__cosf(acosf(cos_in) * 1.002f), 0.0f) / cos_in;
 }
 
 // Bsdf::f(wo, wi, ALL & !SPECULAR) and Bsdf::pdf(wo, wi, ALL & !SPECULAR)
@@ -466,8 +466,8 @@ RRT_DEV LightSample sample_light(const SceneTables* __restrict__ sc, const uint8
     r.delta = true;
   } else if (l.kind == RRT_LIGHT_INFINITE) {
     float st, ct, sp, cp;
-    sincosf(u1 * kPi, &st, &ct);
-    sincosf(u0 * 2.0f * kPi, &sp, &cp);
+    sincos_fast(u1 * kPi, &st, &ct);
+    sincos_fast(u0 * 2.0f * kPi, &sp, &cp);
     r.wi = mk(st * sp, ct, st * cp);
     r.li = env_lookup(sc, env, normalize(r.wi));
     r.pdf = st != 0.0f ? vmax(r.li) / (2.0f * kPi * kPi * st) : 0.0f;
