@@ -285,11 +285,13 @@ struct Collapser {
         node.child[i] = c[i].ref;  // inner references are patched below
       } else {
         for (int k = 0; k < 3; ++k) { node.qlo[k][i] = 255; node.qhi[k][i] = 0; }
-        node.child[i] = kAbsentChild;
+        node.child[i] = ~0;  // replaced by child 0's link below (stays as it is in a scene without triangles, which is never traversed)
       }
     }
     for (int i = 0; i < n; ++i)
       if (c[i].inner) node.child[i] = (int32_t)emit((uint32_t)c[i].ref, depth + 1);
+    if (!empty)
+      for (int i = n; i < 4; ++i) node.child[i] = node.child[0];
     out[me] = node;
     return me;
   }
@@ -407,7 +409,7 @@ struct Validator {
     if ((uint32_t)ref >= b.n_nodes || depth > b.max_depth) { ++bad; return; }
     const BvhNode& n = b.nodes[ref];
     for (int i = 0; i < 4; ++i) {
-      if (n.child[i] == kAbsentChild) continue;
+      if (!child_present(n, i)) continue;
       double cmn[3], cmx[3], dmn[3], dmx[3];
       bounds(n.child[i], depth + (n.child[i] >= 0 ? 1 : 0), cmn, cmx);
       decoded_box(n, i, dmn, dmx);

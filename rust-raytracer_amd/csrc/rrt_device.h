@@ -22,7 +22,10 @@ namespace rrt {
 // 8-bit offsets from the node's own corner: plane = origin[k] + q * 2^(exp[k] - 127), rounded outwards
 // by the builder, so a decoded box always contains the exact one (at most 1/255 of the node's extent
 // looser per side).  child >= 0: index of an inner node.  child < 0: a leaf of 1..4 triangles of the
-// leaf-ordered triangle arrays, ~child = first << 2 | (count - 1).  kAbsentChild: no such child.
+// leaf-ordered triangle arrays, ~child = first << 2 | (count - 1).  A slot without a child holds an
+// inverted box (qlo = 255, qhi = 0 on every axis), which no ray enters, and repeats the link of
+// child 0: should rounding ever let a ray into it -- only a node without any extent can -- the ray
+// visits that child twice, which is harmless.
 // Four wide rather than two: half the steps per ray.  Compressed rather than six floats per child:
 // what bounds traversal is the number of 16-byte loads the lanes of a wave issue to scattered
 // addresses -- the memory pipeline of a CU retires about one such load per lane and clock, whatever
@@ -37,7 +40,7 @@ struct alignas(64) BvhNode {
   uint32_t pad1[2];
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
-constexpr int32_t kAbsentChild = INT32_MIN;
+RRT_HD inline bool child_present(const BvhNode& n, int i) { return n.qlo[0][i] <= n.qhi[0][i]; }
 
 // Intersection record of a triangle, 48 B, leaf order: vertex 0 and the two
 // edges Moeller-Trumbore needs.  v0.w carries the scene-order object id.

@@ -75,13 +75,14 @@ RRT_DEV RayPre prepare_ray(V3 o, V3 d) {
   return r;
 }
 
-// Entry distance of the ray into a child's box from the distances to its six planes, or +inf when
-// the ray misses the box within [tmin, tmax] or the node has no such child.
-RRT_DEV float child_entry(float x0, float x1, float y0, float y1, float z0, float z1, float tmin, float tmax, int child) {
-  const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-  const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+// Entry distance of the ray into a child's box from the distances to the three planes it meets
+// first and the three it meets last, or +inf when the ray misses the box within [tmin, tmax].  A
+// slot without a child holds an inverted box (every maximum below its minimum): it always misses.
+RRT_DEV float child_entry(float nx, float ny, float nz, float fx, float fy, float fz, float tmin, float tmax) {
+  const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+  const float tf = fminf(fminf(fx, fy), fminf(fz, tmax));
   // widen by a few ulps so that rounding never rejects a box the exact test would enter
-  return (tn <= tf * 1.0000005f && child != kAbsentChild) ? tn : INFINITY;
+  return tn <= tf * 1.0000005f ? tn : INFINITY;
 }
 
 // Moeller-Trumbore on an already loaded record.  Accepts t in (tmin, tmax); barycentrics u
@@ -201,10 +202,9 @@ struct Ray {
   } while (0)
 // Distance along the ray to plane q of an axis: (origin + q * step - o) / d = q * (step / d) + (origin - o) / d.
 #define RRT_Q(w, i) ((float)(((w) >> (8 * (i))) & 0xffu))
-#define RRT_CHILD_T(i, c)                                                                \
-  child_entry(fmaf(RRT_Q(w2.x, i), ax, bx), fmaf(RRT_Q(w2.w, i), ax, bx),                \
-              fmaf(RRT_Q(w2.y, i), ay, by), fmaf(RRT_Q(w3.x, i), ay, by),                \
-              fmaf(RRT_Q(w2.z, i), az, bz), fmaf(RRT_Q(w3.y, i), az, bz), tmin, tmax, c)
+#define RRT_CHILD_T(i)                                                                   \
+  child_entry(fmaf(RRT_Q(nx_, i), ax, bx), fmaf(RRT_Q(ny_, i), ay, by), fmaf(RRT_Q(nz_, i), az, bz), \
+              fmaf(RRT_Q(fx_, i), ax, bx), fmaf(RRT_Q(fy_, i), ay, by), fmaf(RRT_Q(fz_, i), az, bz), tmin, tmax)
 #define RRT_NODE_STEP(w0, w1, w2, w3)                                                    \
   do {                                                                                   \
     RRT_DBG_STEP();                                                                      \
@@ -215,11 +215,16 @@ struct Ray {
     const float bx = fmaf(__uint_as_float(w0.x), r.inv.x, -r.ood.x);                     \
     const float by = fmaf(__uint_as_float(w0.y), r.inv.y, -r.ood.y);                     \
     const float bz = fmaf(__uint_as_float(w0.z), r.inv.z, -r.ood.z);                     \
+    /* per axis the ray meets the minimum plane first if it runs upwards, else the maximum plane */ \
+    const bool ux_ = r.inv.x >= 0.0f, uy_ = r.inv.y >= 0.0f, uz_ = r.inv.z >= 0.0f;      \
+    const uint32_t nx_ = ux_ ? w2.x : w2.w, fx_ = ux_ ? w2.w : w2.x;                     \
+    const uint32_t ny_ = uy_ ? w2.y : w3.x, fy_ = uy_ ? w3.x : w2.y;                     \
+    const uint32_t nz_ = uz_ ? w2.z : w3.y, fz_ = uz_ ? w3.y : w2.z;                     \
     int c0 = (int)w1.x, c1 = (int)w1.y, c2 = (int)w1.z, c3 = (int)w1.w;                  \
-    float t0 = RRT_CHILD_T(0, c0);                                                       \
-    float t1 = RRT_CHILD_T(1, c1);                                                       \
-    float t2 = RRT_CHILD_T(2, c2);                                                       \
-    float t3 = RRT_CHILD_T(3, c3);                                                       \
+    float t0 = RRT_CHILD_T(0);                                                           \
+    float t1 = RRT_CHILD_T(1);                                                           \
+    float t2 = RRT_CHILD_T(2);                                                           \
+    float t3 = RRT_CHILD_T(3);                                                           \
     /* sort the four by entry distance (misses are +inf and end up last) */              \
     RRT_CSWAP(t0, c0, t1, c1);                                                           \
     RRT_CSWAP(t2, c2, t3, c3);                                                           \
