@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--cpu-paths", type=int, default=0, help="CPU baseline: camera paths when --cpu-seconds is 0 (both 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--batch-samples", type=int, default=0)
-    ap.add_argument("--max-slots", type=int, default=0, help="paths in flight (0 = library default, 32 Mi)")
+    ap.add_argument("--max-slots", type=int, default=0, help="paths in flight (0 = library default: sized from free device memory)")
     ap.add_argument("--no-calibrate", action="store_true")
     ap.add_argument("--workload", choices=["buddha", "stress"], default="buddha",
                     help="buddha: the headline configuration; stress: cow/lamp/teapot trios on a grid (depth 16)")
@@ -229,9 +229,11 @@ def main():
                        entry("k_connect", 2, st.rays_shadow, st.launches_extend + st.launches_primary, st.ms_connect)]
             # the dominant kernel by time: k_extend (continuation rays)
             e = kernels[1]
+            # measured with the PMC counters on the default workload (tools/profile_bench.sh): no figure for others
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
-            if os.path.exists(tpath):
+            default_workload = args.workload == "buddha" and (args.width, args.height, args.spp) == (1920, 1080, 256)
+            if default_workload and os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic = json.load(f).get("hbm_bytes_per_launch")
             roofline = {"kernel": "k_extend", "bound": "hbm", "achieved": e["algorithmic_gb_per_s"], "peak": HBM_PEAK_GBS,
