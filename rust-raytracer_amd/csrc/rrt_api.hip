@@ -976,11 +976,17 @@ int rrt_get_stats(rrt_ctx* ctx, rrt_stats* out) {
   out->bvh_bytes = ctx->bvh_bytes;
 #ifdef RRT_PHASE_CLOCKS
   {
-    unsigned long long dbg[32];
+    unsigned long long dbg[96];
     if (hipMemcpyFromSymbol(dbg, HIP_SYMBOL(rrt_phase_dbg), sizeof(dbg)) == hipSuccess) {
-      for (int k = 0; k < 32; k += 16)
+      for (int k = 0; k < 96; k += 32) {
         std::fprintf(stderr, "phase clocks (%s): refill %llu (advance %llu begin %llu flush %llu) node %llu leaf %llu | node iters %llu leaf iters %llu | lanes stepping %llu at leaf %llu | refills %llu total %llu | longest ray %llu node steps, %llu rays above 256, %llu above 1024\n",
-                     k ? "any hit" : "closest hit", dbg[k + 0], dbg[k + 10], dbg[k + 11], dbg[k + 12], dbg[k + 1], dbg[k + 2], dbg[k + 3], dbg[k + 4], dbg[k + 5], dbg[k + 6], dbg[k + 7], dbg[k + 8], dbg[k + 13], dbg[k + 14], dbg[k + 15]);
+                     k == 0 ? "continuation rays" : k == 32 ? "visibility rays" : "camera rays", dbg[k + 0], dbg[k + 10], dbg[k + 11], dbg[k + 12], dbg[k + 1], dbg[k + 2], dbg[k + 3], dbg[k + 4], dbg[k + 5], dbg[k + 6], dbg[k + 7], dbg[k + 8], dbg[k + 13], dbg[k + 14], dbg[k + 15]);
+        std::fprintf(stderr, "  node iterations by lanes stepping (1-8 ... 57-64):");
+        for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %llu", dbg[k + 16 + i]);
+        std::fprintf(stderr, "\n  leaf iterations by lanes at a leaf:");
+        for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %llu", dbg[k + 24 + i]);
+        std::fprintf(stderr, "\n");
+      }
       std::memset(dbg, 0, sizeof(dbg));
       (void)hipMemcpyToSymbol(HIP_SYMBOL(rrt_phase_dbg), dbg, sizeof(dbg));
     }

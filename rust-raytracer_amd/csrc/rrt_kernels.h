@@ -406,6 +406,7 @@ RRT_DEV uint32_t grab_size(uint32_t longest, uint32_t waves) {
 // Continuation rays of `parity` first (they take longest), camera rays behind them.
 template <bool COUNT>
 struct ExtendJob {
+  static constexpr int kDebugRow = 0;  // row of the diagnostic build's counters
   const RenderParams& p;
   const SceneTables* sc;  // LDS copy of the shapes
   const uint32_t* lens_c;
@@ -495,6 +496,7 @@ __global__ void __launch_bounds__(kTraceBlock, RRT_EXTEND_WAVES) k_extend(Render
 // three quarters of the bench scene's paths then cost one 16-byte store.
 template <bool COUNT>
 struct PrimaryJob {
+  static constexpr int kDebugRow = 2;  // row of the diagnostic build's counters
   const RenderParams& p;
   const CameraParams& cam;
   const SceneTables* sc;  // LDS copy of the shapes
@@ -700,6 +702,7 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
 // One job = one shadow-queue entry: its light-sample ray, then its environment escape ray, then
 // the clamp; all by one lane, so the sum keeps the order of the reference's loop body.
 struct ConnectJob {
+  static constexpr int kDebugRow = 1;  // row of the diagnostic build's counters
   const RenderParams& p;
   const SceneTables* sc;  // LDS copy of the shapes
   const uint32_t* lens;
@@ -878,6 +881,7 @@ __global__ void k_pass_stats(RenderParams p) {
 
 // ---------------------------------------------------------------- parity hooks
 struct IntersectJob {
+  static constexpr int kDebugRow = 0;  // row of the diagnostic build's counters
   const TriIsect* tris;
   const SceneTables* sc;
   const float* org_dir;
@@ -925,6 +929,7 @@ __global__ void RRT_TRACE_BOUNDS k_intersect(const BvhNode* nodes, const TriIsec
 }
 
 struct OccludedJob {
+  static constexpr int kDebugRow = 1;  // row of the diagnostic build's counters
   const SceneTables* sc;
   const float* odt;
   uint8_t* out;

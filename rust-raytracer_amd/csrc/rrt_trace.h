@@ -126,7 +126,8 @@ struct TraceCounters {
 //   0 refill cycles  1 node-phase cycles  2 leaf-phase cycles  3 node iterations  4 leaf iterations
 //   5 lanes stepping (sum over node iterations)  6 lanes at a leaf (sum over leaf iterations)  7 refills
 //   8 total wave cycles  9 triangle-loop trips
-__device__ unsigned long long rrt_phase_dbg[32];  // closest-hit launches in [0, 16), any-hit in [16, 32)
+//   16..23 node iterations by lanes stepping (1-8, 9-16, ... 57-64)   24..31 leaf iterations by lanes at a leaf
+__device__ unsigned long long rrt_phase_dbg[96];  // rows of 32: continuation / hook rays, visibility rays, camera rays (Job::kDebugRow)
 #define RRT_CLK() __builtin_readcyclecounter()
 #define RRT_DBG_ADD(i, v) do { if (lane == 0) dbg[i] += (v); } while (0)
 #else
@@ -267,7 +268,7 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
   hit.u = hit.v = 0.0f;
   bool found = false;
 #ifdef RRT_PHASE_CLOCKS
-  unsigned long long dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg[32] = {};
   unsigned long long clk2 = 0;
   uint32_t lane_steps = 0;
   const unsigned long long clk_begin = RRT_CLK();
@@ -279,9 +280,9 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
 #define RRT_DBG_STEP() ++lane_steps
 #define RRT_DBG_RAY_END()                                                                              \
   do {                                                                                                 \
-    atomicMax(&rrt_phase_dbg[(ANY ? 16 : 0) + 13], (unsigned long long)lane_steps);                     \
-    if (lane_steps > 256) atomicAdd(&rrt_phase_dbg[(ANY ? 16 : 0) + 14], 1ull);                         \
-    if (lane_steps > 1024) atomicAdd(&rrt_phase_dbg[(ANY ? 16 : 0) + 15], 1ull);                        \
+    atomicMax(&rrt_phase_dbg[(32 * Job::kDebugRow) + 13], (unsigned long long)lane_steps);                     \
+    if (lane_steps > 256) atomicAdd(&rrt_phase_dbg[(32 * Job::kDebugRow) + 14], 1ull);                         \
+    if (lane_steps > 1024) atomicAdd(&rrt_phase_dbg[(32 * Job::kDebugRow) + 15], 1ull);                        \
   } while (0)
 #else
 #define RRT_DBG_RAY_BEGIN() do { } while (0)
@@ -459,6 +460,9 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
       for (;;) {
         for (;;) {
           RRT_DBG_ADD(5, __popcll(__ballot(state == kTravelling && cur >= 0)));
+#ifdef RRT_PHASE_CLOCKS
+          { const int n_ = __popcll(__ballot(state == kTravelling && cur >= 0)); if (n_ > 0) RRT_DBG_ADD(16 + (n_ - 1) / 8, 1); }
+#endif
           if (state == kTravelling && cur >= 0) {
             const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
             uint4 w0, w1, w2, w3;
@@ -472,7 +476,8 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
         }
 #ifdef RRT_PHASE_CLOCKS
         { const unsigned long long now = RRT_CLK(); RRT_DBG_ADD(1, now - clk); clk = now;
-          RRT_DBG_ADD(4, 1); RRT_DBG_ADD(6, __popcll(__ballot(state == kTravelling && cur < 0))); }
+          RRT_DBG_ADD(4, 1); RRT_DBG_ADD(6, __popcll(__ballot(state == kTravelling && cur < 0)));
+          { const int n_ = __popcll(__ballot(state == kTravelling && cur < 0)); if (n_ > 0) RRT_DBG_ADD(24 + (n_ - 1) / 8, 1); } }
 #endif
         if (state == kTravelling && cur < 0) {
           // leaf: ~cur = first << 2 | (count - 1)
@@ -510,7 +515,8 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
 #ifdef RRT_PHASE_CLOCKS
   if (lane == 0) {
     dbg[8] = RRT_CLK() - clk_begin;
-    for (int i = 0; i < 13; ++i) atomicAdd(&rrt_phase_dbg[(ANY ? 16 : 0) + i], dbg[i]);
+    for (int i = 0; i < 32; ++i)
+      if (i < 13 || i >= 16) atomicAdd(&rrt_phase_dbg[(32 * Job::kDebugRow) + i], dbg[i]);
   }
 #endif
 #undef RRT_START_RAY
