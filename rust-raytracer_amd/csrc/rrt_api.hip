@@ -31,6 +31,9 @@ constexpr double kAutoMemoryShare = RRT_AUTO_MEMORY_SHARE;  // automatic pool si
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxSlotsPerPixel = 1024;
 constexpr uint32_t kQueueGridBlocks = 8192;  // 32 blocks per CU for the kernels that walk a queue chunk by chunk
+#ifndef RRT_OVERLAP_FROM
+#define RRT_OVERLAP_FROM 1   // first iteration whose visibility rays run beside the next extend (-1: never)
+#endif
 #ifndef RRT_TRACE_GRID
 #define RRT_TRACE_GRID 2048
 #endif
@@ -48,6 +51,8 @@ struct EventPair {
 struct rrt_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side_stream = nullptr;          // visibility rays of late iterations run here, beside the next extend
+  hipEvent_t ev_shade = nullptr, ev_connect = nullptr;
   std::string error;
 
   // scene
@@ -286,7 +291,7 @@ DeviceMaterial digest_material(const rrt_material& m) {
   return d;
 }
 
-int record_begin(rrt_ctx* ctx, int stage) {
+int record_begin(rrt_ctx* ctx, int stage, hipStream_t stream) {
   if (!ctx->timing) return RRT_OK;
   if (ctx->events_used == ctx->events.size()) {
     EventPair ep;
@@ -295,20 +300,22 @@ int record_begin(rrt_ctx* ctx, int stage) {
     ctx->events.push_back(ep);
   }
   ctx->events[ctx->events_used].stage = stage;
-  HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].begin, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].begin, stream));
   return RRT_OK;
 }
+int record_begin(rrt_ctx* ctx, int stage) { return record_begin(ctx, stage, ctx->stream); }
 
-int record_end(rrt_ctx* ctx) {
+int record_end(rrt_ctx* ctx, hipStream_t stream) {
   if (!ctx->timing) return RRT_OK;
-  HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].end, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used].end, stream));
   ctx->events_used++;
   return RRT_OK;
 }
+int record_end(rrt_ctx* ctx) { return record_end(ctx, ctx->stream); }
 
 int collect_timing(rrt_ctx* ctx) {
   if (!ctx->timing || ctx->events_used == 0) return RRT_OK;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (work on the side stream has been joined by then)
   for (size_t i = 0; i < ctx->events_used; ++i) {
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->events[i].begin, ctx->events[i].end));
@@ -338,13 +345,29 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
   p.single = per_slot == 1 && !p.filter_table ? 1u : 0u;
   // a slot needs at least one iteration per sample plus one to retire, at most depth_limit per sample
   const uint64_t max_iterations = (uint64_t)per_slot * p.depth_limit + 2;
+  // Late iterations hold few rays and each launch waits for its longest one: from iteration
+  // RRT_OVERLAP_FROM on, the visibility rays of an iteration run on a second stream beside the start
+  // and extend of the next (shade joins them again: it rewrites the records connect reads).  Only
+  // with one sample per slot: a regenerating slot's start banks the radiance connect is still adding to.
+  const bool may_overlap = p.single != 0 && RRT_OVERLAP_FROM >= 0;
+  if (may_overlap && !ctx->side_stream) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_shade, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_connect, hipEventDisableTiming));
+  }
+  bool connect_outstanding = false;  // a connect on the side stream that the main stream has not joined yet
   uint64_t it = 0;
   uint32_t burst = per_slot + 1;
   for (;;) {
     for (uint32_t j = 0; j < burst; ++j, ++it) {
       const uint32_t parity = (uint32_t)(it & 1), next = parity ^ 1u;
-      // camera, shade, shadow and the two queues of the other parity start this iteration empty
-      HIP_TRY(ctx, hipMemsetAsync(p.a.counters + row_words * 2 * next, 0, row_bytes * kRowsPerIteration, ctx->stream));
+      // camera, shade and the two queues of the other parity start this iteration empty
+      if (next == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(p.a.counters, 0, row_bytes * kRowShadow, ctx->stream));
+      } else {
+        HIP_TRY(ctx, hipMemsetAsync(p.a.counters + row_words * kRowCamera, 0, row_bytes * (kRowShadow - kRowCamera), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(p.a.counters + row_words * kRowStart1, 0, row_bytes * 2, ctx->stream));
+      }
       if (it == 0) {
         // the first camera ray of every slot: generated and traced by one kernel
         if ((rc = record_begin(ctx, 5)) != RRT_OK) return rc;
@@ -360,15 +383,32 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
         else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, parity);
         if ((rc = record_end(ctx)) != RRT_OK) return rc;
       }
+      if (connect_outstanding) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_connect, 0));
+        connect_outstanding = false;
+      }
+      // the visibility stage's queue and cursor
+      HIP_TRY(ctx, hipMemsetAsync(p.a.counters + row_words * kRowShadow, 0, row_bytes * 2, ctx->stream));
       if ((rc = record_begin(ctx, 2)) != RRT_OK) return rc;
       hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, ctx->stream, p, parity);
       if ((rc = record_end(ctx)) != RRT_OK) return rc;
-      if ((rc = record_begin(ctx, 3)) != RRT_OK) return rc;
-      if (ctx->count_traversal) hipLaunchKernelGGL(k_connect<true>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p);
-      else hipLaunchKernelGGL(k_connect<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p);
-      if ((rc = record_end(ctx)) != RRT_OK) return rc;
+      hipStream_t connect_stream = ctx->stream;
+      if (may_overlap && it >= (uint64_t)RRT_OVERLAP_FROM) {
+        connect_stream = ctx->side_stream;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_shade, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(connect_stream, ctx->ev_shade, 0));
+      }
+      if ((rc = record_begin(ctx, 3, connect_stream)) != RRT_OK) return rc;
+      if (ctx->count_traversal) hipLaunchKernelGGL(k_connect<true>, dim3(trace_grid), dim3(kBlock), 0, connect_stream, p);
+      else hipLaunchKernelGGL(k_connect<false>, dim3(trace_grid), dim3(kBlock), 0, connect_stream, p);
+      if ((rc = record_end(ctx, connect_stream)) != RRT_OK) return rc;
+      if (connect_stream != ctx->stream) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_connect, connect_stream));
+        connect_outstanding = true;
+      }
     }
     // rows start/cont of the parity the next iteration would read sit next to each other
+    // (extend and shade fill them: a connect still running on the side stream does not touch them)
     const uint32_t parity = (uint32_t)(it & 1);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pending, p.a.counters + row_words * (parity ? kRowStart1 : kRowStart0), row_bytes * 2,
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -379,6 +419,7 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
     if (it >= max_iterations) return fail(ctx, RRT_E_DEVICE, "path queues did not drain");
     burst = (uint32_t)std::min<uint64_t>(4, max_iterations - it);
   }
+  if (connect_outstanding) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_connect, 0));
   if ((rc = record_begin(ctx, 4)) != RRT_OK) return rc;
   // with a reconstruction filter the samples went into the film as their paths ended
   if (!p.filter_table) {
@@ -447,6 +488,12 @@ void rrt_destroy(rrt_ctx* ctx) {
   for (EventPair& e : ctx->events) {
     (void)hipEventDestroy(e.begin);
     (void)hipEventDestroy(e.end);
+  }
+  if (ctx->side_stream) {
+    (void)hipStreamSynchronize(ctx->side_stream);
+    (void)hipStreamDestroy(ctx->side_stream);
+    (void)hipEventDestroy(ctx->ev_shade);
+    (void)hipEventDestroy(ctx->ev_connect);
   }
   delete ctx;
 }

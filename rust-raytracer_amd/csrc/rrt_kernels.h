@@ -73,10 +73,13 @@ constexpr uint32_t kEscaped = 0x40000000u;  // the path ended because its ray le
 constexpr uint32_t kSlotMask = 0x3fffffffu;
 
 // Counter rows.  The queues written during iteration i for iteration i + 1 use parity (i + 1) & 1;
-// rows [2 * parity, 2 * parity + 7) are exactly the ones to zero before iteration i starts.
+// rows [2 * parity, 2 * parity + 7) are exactly the ones an iteration starts with at zero: all but the
+// two of the visibility stage are cleared before iteration i starts, those two (kRowShadow,
+// kRowWorkConnect) just before its shade -- the visibility rays of iteration i - 1 may still be running
+// beside the start and extend of iteration i.
 // A work row holds one word: the cursor from which a traversal kernel's waves take their jobs.
 enum : uint32_t {
-  kRowStart0 = 0, kRowCont0 = 1, kRowCamera = 2, kRowShade = 3, kRowShadow = 4, kRowWorkExtend = 5, kRowWorkConnect = 6,
+  kRowStart0 = 0, kRowCont0 = 1, kRowCamera = 2, kRowShade = 3, kRowWorkExtend = 4, kRowShadow = 5, kRowWorkConnect = 6,
   kRowStart1 = 7, kRowCont1 = 8,
   kRowsPerIteration = 7,
   // running totals over the whole pass (never reset between iterations)
