@@ -679,6 +679,10 @@ int rrt_set_camera(rrt_ctx* ctx, const double raster_to_camera[16], const double
   std::memcpy(ctx->camera.camera_to_world, camera_to_world, sizeof(double) * 16);
   ctx->camera.aperture = aperture;
   ctx->camera.focal_distance = focal_distance;
+  {
+    const double* m = ctx->camera.raster_to_camera;
+    ctx->camera.const_inv_w = (m[12] == 0.0 && m[13] == 0.0 && m[15] != 0.0) ? 1.0 / m[15] : 0.0;
+  }
   ctx->have_camera = true;
   return RRT_OK;
 }
@@ -881,6 +885,7 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
   p.win_w = win_w;
   p.win_h = win_h;
   p.tiles_x = tiles_x;
+  p.div_tiles_x = make_fast_div(tiles_x);
   p.depth_limit = s->depth_limit;
   p.clamp = (float)s->clamp;
   p.filter_table = ctx->filter_method != RRT_FILTER_NONE ? ctx->d_filter_table : nullptr;
@@ -891,6 +896,7 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
     p.sample_begin = sample_begin;
     p.sample_end = sample_end;
     p.n_samples = k;
+    p.div_samples = make_fast_div(k);
     p.n_slots = p.n_tiles * 64 * k;
     if ((rc = launch_pass(ctx, p)) != RRT_OK) return rc;
     // the primary kernel traced one ray for every slot of a pixel inside the window

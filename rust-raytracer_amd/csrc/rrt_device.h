@@ -131,6 +131,7 @@ struct CameraParams {
   double raster_to_camera[16];
   double camera_to_world[16];
   double aperture, focal_distance;
+  double const_inv_w;  // 1 / w of raster_to_camera * (x, y, 0, 1) when that w does not depend on x and y (any perspective or orthographic projection), else 0
 };
 
 // Host BVH builder (bvh_build.cpp).  Produces nodes and the leaf order.

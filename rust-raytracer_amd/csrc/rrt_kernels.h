@@ -128,6 +128,22 @@ struct PathArrays {
   uint32_t seg_cap;      // capacity of one queue segment
 };
 
+// Division of x < 2^31 by a run-time constant d >= 1 without the 20-instruction division sequence
+// (Granlund & Montgomery): with l = ceil(log2 d) and m = floor(2^32 (2^l - d) / d) + 1,
+// floor(x / d) = (mulhi(m, x) + x) >> l.  Slot, pixel and tile numbers stay below 2^30.
+struct FastDiv {
+  uint32_t m, shift, d;
+};
+inline FastDiv make_fast_div(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  f.shift = 0;
+  while ((1ull << f.shift) < d) ++f.shift;
+  f.m = (uint32_t)((((1ull << f.shift) - d) << 32) / d + 1ull);
+  return f;
+}
+RRT_DEV uint32_t fast_div(uint32_t x, const FastDiv& f) { return (__umulhi(f.m, x) + x) >> f.shift; }
+
 struct RenderParams {
   PathArrays a;
   const BvhNode* nodes;
@@ -142,6 +158,7 @@ struct RenderParams {
   uint32_t width, height;           // film size
   uint32_t win_x0, win_y0, win_w, win_h;  // render window
   uint32_t tiles_x;                 // 8x8 pixel tiles per window row
+  FastDiv div_tiles_x, div_samples; // divisions by tiles_x and n_samples
   uint32_t tile_begin, n_tiles;     // tiles of this pass
   uint32_t sample_begin, sample_end;
   uint32_t n_samples;               // K: slots per pixel
@@ -163,10 +180,10 @@ RRT_DEV uint32_t* counter_at(uint32_t* counters, uint32_t row, uint32_t seg) {
 // slot -> pixel and the slot's lane k among the pixel's K slots.  Consecutive slots share a pixel;
 // consecutive pixels walk an 8x8 tile.
 RRT_DEV bool slot_pixel(const RenderParams& p, uint32_t slot, uint32_t* x, uint32_t* y, uint32_t* k) {
-  const uint32_t pix = slot / p.n_samples;
-  *k = slot % p.n_samples;
+  const uint32_t pix = fast_div(slot, p.div_samples);
+  *k = slot - pix * p.n_samples;
   const uint32_t tile = p.tile_begin + pix / 64, in = pix % 64;
-  const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+  const uint32_t ty = fast_div(tile, p.div_tiles_x), tx = tile - ty * p.tiles_x;
   const uint32_t lx = tx * 8 + (in & 7), ly = ty * 8 + (in >> 3);
   *x = p.win_x0 + lx;
   *y = p.win_y0 + ly;
@@ -270,8 +287,11 @@ RRT_DEV void camera_ray(const CameraParams& cam, uint32_t x, uint32_t y, const R
   const double fx = (double)x + (double)r.u[0], fy = (double)y + (double)r.u[1];
   const double* m = cam.raster_to_camera;
   const double cx = m[0] * fx + m[1] * fy + m[3], cy = m[4] * fx + m[5] * fy + m[7], cz = m[8] * fx + m[9] * fy + m[11];
-  const double cw = m[12] * fx + m[13] * fy + m[15];
-  const double iw = cw != 0.0 ? 1.0 / cw : 1.0;
+  double iw = cam.const_inv_w;  // the same 1 / w for every pixel of a projective camera: no division per ray
+  if (iw == 0.0) {
+    const double cw = m[12] * fx + m[13] * fy + m[15];
+    iw = cw != 0.0 ? 1.0 / cw : 1.0;
+  }
   V3 d = mk((float)(cx * iw), (float)(cy * iw), (float)(cz * iw));
   V3 o = mk(0.0f, 0.0f, 0.0f);
   if (cam.aperture > 0.0) {
@@ -541,7 +561,7 @@ struct PrimaryJob {
     } else if (single) {
       // a camera ray that escapes sees the lights' environment term (src/tracer.rs:50-53): the
       // slot's only path is complete
-      p.a.radiance[slot] = f4(escape_radiance(p.scene, p.env, r.d), 0.0f);
+      p.a.radiance[slot] = f4(escape_radiance(sc, p.env, r.d), 0.0f);  // (the fields it reads lie in the LDS copy)
       kind = 0;
     } else {
       p.a.trace[slot].ray_d = f4(r.d, __uint_as_float(0u));

@@ -88,6 +88,27 @@ def test_hierarchy_invariants(rrt):
             assert n_nodes < len(tris) and depth < 64, (name, n_nodes, depth)
 
 
+def test_fast_division_formula():
+    """The kernels divide slot and tile numbers (< 2^30) by run-time constants as
+    (mulhi(m, x) + x) >> l with l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1 (csrc/rrt_kernels.h,
+    FastDiv): exact for every divisor, checked here on the edges and on random pairs in 64-bit integers."""
+    rng = np.random.default_rng(3)
+    ds = np.concatenate([np.arange(1, 300), 2 ** np.arange(0, 21), 2 ** np.arange(1, 21) - 1, 2 ** np.arange(1, 21) + 1,
+                         rng.integers(1, 1 << 20, 2000)]).astype(np.uint64)
+    for d in ds:
+        l = int(np.ceil(np.log2(float(d)))) if d > 1 else 0
+        while (1 << l) < int(d):
+            l += 1
+        m = (((1 << l) - int(d)) << 32) // int(d) + 1
+        assert m < (1 << 32)
+        xs = np.concatenate([np.arange(0, 70), int(d) * np.arange(0, 50) + np.array([-1, 0, 1]).reshape(3, 1).repeat(50, 1).ravel()[:50] ,
+                             rng.integers(0, 1 << 30, 300), np.array([(1 << 30) - 1, (1 << 30)])])
+        xs = xs[(xs >= 0) & (xs <= (1 << 30))].astype(np.uint64)
+        q = (((np.uint64(m) * xs) >> np.uint64(32)) + xs) >> np.uint64(l)
+        assert (q < (1 << 32)).all()
+        np.testing.assert_array_equal(q, xs // d)
+
+
 def test_cornell_scene(rrt, cornell):
     scene, rs = cornell
     d = scene.desc()
