@@ -240,8 +240,11 @@ int64_t rrt_bvh_selfcheck(const float* tri_pos, uint32_t n_tris, uint32_t* n_nod
 /* Options. */
 enum {
   RRT_OPT_TIMING = 1,          /* 1: time each kernel with HIP events (the host waits at the end of every pass) */
-  RRT_OPT_BATCH_SAMPLES = 2,   /* path slots per pixel (each works through its share of the samples; 0 = automatic) */
-  RRT_OPT_MAX_SLOTS = 3,       /* upper bound on paths in flight (sizes the path-state arrays; at most 2^30) */
+  RRT_OPT_BATCH_SAMPLES = 2,   /* path slots per pixel, each working through its share of the samples in place (0 = automatic:
+                                  one slot per sample if memory allows, else rounds of one sample per slot, and slots that
+                                  work through several samples only below 16 slots per pixel) */
+  RRT_OPT_MAX_SLOTS = 3,       /* upper bound on paths in flight (sizes the path-state arrays; at most 2^30; 0 = 60 % of the
+                                  free device memory) */
   RRT_OPT_COUNT_TRAVERSAL = 4  /* 1: count nodes_visited / tris_tested (slower kernels; for calibration runs) */
 };
 int rrt_set_option(rrt_ctx* ctx, int option, int64_t value);

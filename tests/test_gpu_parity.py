@@ -400,6 +400,45 @@ def test_full_size_schedule_independence(rrt, buddha, gpu_ctx):
         assert rel <= 1e-5, name
 
 
+def test_rounds_of_one_sample_per_slot(rrt, cornell, gpu_ctx):
+    """A pool that holds 20 of a pixel's 64 samples: the library renders four rounds of 16 samples, one
+    per slot (not slots that work through several samples).  Same paths, same film up to summation order;
+    two calls over adjacent sample ranges compose to the same film as well."""
+    scene, rs = cornell
+    w, h, spp = 160, 120, 64
+    cam = rrt.Camera.from_settings(rs, w, h)
+    s = rrt.make_settings(w, h, rs.depth_limit, rs.clamp, seed=5)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    gpu_ctx.reset_stats()
+    gpu_ctx.render(s, 0, spp)
+    whole = gpu_ctx.film_download().astype(np.float64)
+    assert gpu_ctx.stats().paths == w * h * spp
+    try:
+        gpu_ctx.set_option(rrt.OPT_MAX_SLOTS, w * h * 20)
+        gpu_ctx.set_option(rrt.OPT_TIMING, 1)  # launches are counted from the timing events
+        gpu_ctx.film_clear()
+        gpu_ctx.reset_stats()
+        gpu_ctx.render(s, 0, spp)
+        gpu_ctx.set_option(rrt.OPT_TIMING, 0)
+        rounds = gpu_ctx.film_download().astype(np.float64)
+        st = gpu_ctx.stats()
+        assert st.paths == w * h * spp and st.launches_primary == 4, (st.paths, st.launches_primary)
+        gpu_ctx.film_clear()
+        gpu_ctx.render(s, 0, 23)
+        gpu_ctx.render(s, 23, spp)
+        two_calls = gpu_ctx.film_download().astype(np.float64)
+    finally:
+        gpu_ctx.set_option(rrt.OPT_MAX_SLOTS, 0)
+        gpu_ctx.set_option(rrt.OPT_TIMING, 0)
+    for name, f in (("rounds", rounds), ("two calls", two_calls)):
+        np.testing.assert_array_equal(f[..., 3], whole[..., 3])
+        rel = np.abs(f[..., :3] - whole[..., :3]).max() / whole[..., :3].max()
+        print("%s: max difference %.3g of the film's maximum" % (name, rel))
+        assert rel <= 1e-5, name
+
+
 def test_cpp_host_render(rrt, cornell, gpu_ctx, tmp_path):
     """The C++ host (Scene::load_from_folder, RenderSettingsFile, Camera, render() with its worker
     thread and ThreadMessage channel, Film::merge_accumulators, tone map, PPM / PFM writers) drives
