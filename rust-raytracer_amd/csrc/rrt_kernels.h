@@ -547,7 +547,7 @@ struct PrimaryJob {
     ray->tmin = 0.0f;
     ray->tmax = kTriTMax;
     ray->skip = -1;
-    p.a.sample[slot] = sample;
+    if (!single) p.a.sample[slot] = sample;  // (one sample per slot: shade derives it from the slot number)
     return true;
   }
   RRT_DEV bool advance(bool found, const Hit& tri_hit, const RayPre& r, Ray*) {
@@ -610,6 +610,13 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_primary(RenderParams p, Came
 // ---------------------------------------------------------------- shade
 __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
   __shared__ uint32_t lens[kSegments + 1];
+  // the whole of the small tables in LDS: every lane reads a score of fields of the light it draws
+  __shared__ uint32_t table_words[(sizeof(SceneTables) + 3) / 4];
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.scene);
+    for (uint32_t i = threadIdx.x; i < (sizeof(SceneTables) + 3) / 4; i += blockDim.x) table_words[i] = src[i];
+  }
+  const SceneTables* sc = reinterpret_cast<const SceneTables*>(table_words);  // (queue_lengths below synchronises)
   const uint32_t chunks = queue_blocks(queue_lengths(p, kRowShade, lens), 256);
   const uint32_t next = parity ^ 1u;
   for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
@@ -625,18 +632,18 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
     slot = entries[i];
     const float4 o4 = p.a.trace[slot].ray_o, d4 = p.a.trace[slot].ray_d, h4 = p.a.trace[slot].hit;
     const V3 org = mk(o4), dir = mk(d4);
-    const uint32_t sample = p.a.sample[slot], bounce = __float_as_uint(d4.w) >> 1;
+    uint32_t x, y, k;
+    slot_pixel(p, slot, &x, &y, &k);
+    // with one sample per slot the sample index follows from the slot number
+    const uint32_t sample = p.single ? p.sample_begin + k : p.a.sample[slot], bounce = __float_as_uint(d4.w) >> 1;
     V3 beta = mk(1.0f, 1.0f, 1.0f);
     if (bounce > 0) beta = mk(p.a.trace[slot].beta);
     else p.a.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int prim = __float_as_int(h4.x);
-    const SceneTables* sc = p.scene;
     // AreaLight::emitting is zero (lights/area.rs:23-25): hitting an emitter adds nothing
     const Surface s = prim < sc->n_tris ? surface_triangle(p.tris, p.tri_shade, prim, h4.z, h4.w, dir)
                                         : surface_other(sc, prim, h4.y, org, dir);
     const DeviceMaterial m = p.materials[s.material];
-    uint32_t x, y, k;
-    slot_pixel(p, slot, &x, &y, &k);
     const uint32_t pixel = y * p.width + x;
     const Rng4 ra = rng_block(p.seed, pixel, sample, 1 + 3 * bounce);
 
