@@ -50,7 +50,10 @@ struct Node2 {
   int32_t lcount, rcount;
 };
 
-constexpr int kBins = 16;
+#ifndef RRT_SAH_BINS
+#define RRT_SAH_BINS 16
+#endif
+constexpr int kBins = RRT_SAH_BINS;
 #ifndef RRT_SAH_NODE_COST
 #define RRT_SAH_NODE_COST 1.0  // cost of a traversal step in units of one triangle test
 #endif
