@@ -204,6 +204,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = ctx.stats()
+    # untimed: one more frame with every kernel on the one stream, for the dominant kernel's launch time when it
+    # has the GPU to itself (in the timed frames it shares it with the previous iteration's visibility rays)
+    alone_ms = None
+    if rank == 0 and not args.no_calibrate:
+        keep = film.clone()
+        ctx.set_option(rr.OPT_SIDE_STREAM, 0)
+        ctx.reset_stats()
+        ctx.render(settings, s_begin, s_end)
+        torch.cuda.synchronize(device)
+        st1 = ctx.stats()
+        alone_ms = st1.ms_extend / max(st1.launches_extend, 1)
+        ctx.set_option(rr.OPT_SIDE_STREAM, 1)
+        film.copy_(keep)
     ctx.set_option(rr.OPT_TIMING, 0)
 
     paths_all = float(W) * H * SPP * args.steps * world
@@ -241,6 +254,9 @@ def main():
                         "bytes_per_ray": e["bytes_per_ray"], "nodes_per_ray": e["nodes_per_ray"],
                         "tris_per_ray": e["tris_per_ray"], "launches": e["launches"], "avg_launch_ms": e["avg_launch_ms"],
                         "rays_per_launch": e["rays_per_launch"]}
+            if alone_ms:
+                roofline["avg_launch_ms_alone"] = alone_ms
+                roofline["frac_alone"] = roofline["frac"] * e["avg_launch_ms"] / alone_ms
         out = {
             "metric": "camera-path samples/sec",
             "value": value,

@@ -245,7 +245,11 @@ enum {
                                   work through several samples only below 16 slots per pixel) */
   RRT_OPT_MAX_SLOTS = 3,       /* upper bound on paths in flight (sizes the path-state arrays; at most 2^30; 0 = 60 % of the
                                   free device memory) */
-  RRT_OPT_COUNT_TRAVERSAL = 4  /* 1: count nodes_visited / tris_tested (slower kernels; for calibration runs) */
+  RRT_OPT_COUNT_TRAVERSAL = 4, /* 1: count nodes_visited / tris_tested (slower kernels; for calibration runs) */
+  RRT_OPT_SIDE_STREAM = 5      /* 1 (default): rrt_render runs the visibility rays of an iteration on a stream of its own
+                                  beside the next iteration's closest-hit rays and joins it again before it returns
+                                  work to the caller's stream; 0: everything on the one stream (per-kernel times in
+                                  rrt_stats then do not overlap) */
 };
 int rrt_set_option(rrt_ctx* ctx, int option, int64_t value);
 

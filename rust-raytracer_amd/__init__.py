@@ -91,7 +91,7 @@ class RenderSettingsFile(C.Structure):
 MAT_MATTE, MAT_PLASTIC, MAT_MIRROR, MAT_GLASS = 0, 1, 2, 3
 LIGHT_POINT, LIGHT_AREA, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2, 3
 RECT_AABB_STRICT, RECT_AABB_INCLUSIVE, RECT_AABB_OFF = 0, 1, 2
-OPT_TIMING, OPT_BATCH_SAMPLES, OPT_MAX_SLOTS, OPT_COUNT_TRAVERSAL = 1, 2, 3, 4
+OPT_TIMING, OPT_BATCH_SAMPLES, OPT_MAX_SLOTS, OPT_COUNT_TRAVERSAL, OPT_SIDE_STREAM = 1, 2, 3, 4, 5
 FILTER_NONE, FILTER_GAUSSIAN, FILTER_MITCHELL = 0, 1, 2
 
 # every symbol include/rrt.h and include/rrt_host.h declare

@@ -96,6 +96,7 @@ struct rrt_ctx {
   // options
   bool timing = false;
   bool count_traversal = false;
+  bool side_stream_allowed = true;            // RRT_OPT_SIDE_STREAM
   uint32_t batch_samples = 0;
   uint32_t max_slots = 0;  // 0: sized from the free device memory
 
@@ -350,7 +351,7 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
   // RRT_OVERLAP_FROM on, the visibility rays of an iteration run on a second stream beside the start
   // and extend of the next (shade joins them again: it rewrites the records connect reads).  Only
   // with one sample per slot: a regenerating slot's start banks the radiance connect is still adding to.
-  const bool may_overlap = p.single != 0 && RRT_OVERLAP_FROM >= 0;
+  const bool may_overlap = p.single != 0 && RRT_OVERLAP_FROM >= 0 && ctx->side_stream_allowed;
   if (may_overlap && !ctx->side_stream) {
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_shade, hipEventDisableTiming));
@@ -1010,6 +1011,7 @@ int rrt_set_option(rrt_ctx* ctx, int option, int64_t value) {
       ctx->max_slots = (uint32_t)value;
       return RRT_OK;
     case RRT_OPT_COUNT_TRAVERSAL: ctx->count_traversal = value != 0; return RRT_OK;
+    case RRT_OPT_SIDE_STREAM: ctx->side_stream_allowed = value != 0; return RRT_OK;
     default: return fail(ctx, RRT_E_INVALID, "unknown option");
   }
 }
