@@ -543,12 +543,14 @@ RRT_DEV bool rect_box_pass(const DeviceRect& q, const RayPre& r, int mode) {
 }
 
 // objects/rectangle.rs:58-101
-RRT_DEV bool intersect_rect(const DeviceRect& q, const RayPre& r, float* t_out) {
+// (tmax: hits at or beyond it are of no interest to the caller; most rays of a wave end here, before
+// the sides are looked at)
+RRT_DEV bool intersect_rect(const DeviceRect& q, const RayPre& r, float tmax, float* t_out) {
   const V3 n = mk(q.normal);
   const float denom = dot(n, r.d);
   if (fabsf(denom) < 1e-9f) return false;
   const float t = dot(mk(q.pos) - r.o, n) * __builtin_amdgcn_rcpf(denom);
-  if (t < 1e-9f) return false;
+  if (t < 1e-9f || !(t < tmax)) return false;
   const V3 p0p = r.o + r.d * t - mk(q.pos);
   const float a = dot(p0p, mk(q.a)) * q.inv_aa;
   const float b = dot(p0p, mk(q.b)) * q.inv_bb;
@@ -597,7 +599,7 @@ RRT_DEV bool intersect_others(const SceneTables* __restrict__ sc, const RayPre& 
   for (int i = 0; i < sc->n_rects; ++i, ++code) {
     float t;
     // the quad itself first: few rays pass it, and only those need the box test
-    if (code != skip_a && code != skip_b && intersect_rect(sc->rects[i], r, &t) && t < tmax &&
+    if (code != skip_a && code != skip_b && intersect_rect(sc->rects[i], r, tmax, &t) &&
         rect_box_pass(sc->rects[i], r, sc->rect_aabb_mode)) {
       if (ANY) return true;
       tmax = t; hit->prim = code; hit->t = t; hit->u = 0.0f; hit->v = 0.0f; found = true;
