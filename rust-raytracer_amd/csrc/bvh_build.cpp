@@ -11,7 +11,9 @@
 // depth-first order.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -117,36 +119,43 @@ struct Builder {
     if (depth < kSahDepthLimit) {
       float best_cost = INFINITY;
       int best_axis = -1, best_bin = -1;
+      // one pass over the triangles fills the bins of all three axes
+      Box bin_box[3][kBins];
+      uint32_t bin_cnt[3][kBins];
+      float c0[3], scale[3];
       for (int axis = 0; axis < 3; ++axis) {
-        const float c0 = cbounds.mn[axis], extent = cbounds.mx[axis] - c0;
-        if (!(extent > 0.0f)) continue;
-        const float scale = (float)kBins / extent;
-        Box bin_box[kBins];
-        uint32_t bin_cnt[kBins] = {0};
-        for (int b = 0; b < kBins; ++b) bin_box[b].reset();
-        for (uint32_t i = lo; i < hi; ++i) {
-          const size_t t = (size_t)idx[i] * 3;
-          int b = (int)((cent[t + axis] - c0) * scale);
+        c0[axis] = cbounds.mn[axis];
+        const float extent = cbounds.mx[axis] - c0[axis];
+        scale[axis] = extent > 0.0f ? (float)kBins / extent : 0.0f;  // 0: everything in bin 0, no split on this axis
+        for (int b = 0; b < kBins; ++b) { bin_box[axis][b].reset(); bin_cnt[axis][b] = 0; }
+      }
+      for (uint32_t i = lo; i < hi; ++i) {
+        const size_t t = (size_t)idx[i] * 3;
+        for (int axis = 0; axis < 3; ++axis) {
+          int b = (int)((cent[t + axis] - c0[axis]) * scale[axis]);
           b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-          bin_cnt[b]++;
-          bin_box[b].grow(&tmin[t], &tmax[t]);
+          bin_cnt[axis][b]++;
+          bin_box[axis][b].grow(&tmin[t], &tmax[t]);
         }
+      }
+      for (int axis = 0; axis < 3; ++axis) {
+        if (!(scale[axis] > 0.0f)) continue;
         float right_area[kBins];
         uint32_t right_cnt[kBins];
         Box acc;
         acc.reset();
         uint32_t c = 0;
         for (int b = kBins - 1; b > 0; --b) {
-          acc.grow(bin_box[b]);
-          c += bin_cnt[b];
+          acc.grow(bin_box[axis][b]);
+          c += bin_cnt[axis][b];
           right_area[b] = acc.half_area();
           right_cnt[b] = c;
         }
         acc.reset();
         c = 0;
         for (int b = 0; b < kBins - 1; ++b) {
-          acc.grow(bin_box[b]);
-          c += bin_cnt[b];
+          acc.grow(bin_box[axis][b]);
+          c += bin_cnt[axis][b];
           if (c == 0 || right_cnt[b + 1] == 0) continue;
           const float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
           if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
@@ -211,11 +220,15 @@ struct Builder {
   }
 };
 
-// Collapses the binary tree into 4-wide nodes, emitted in depth-first pre-order.
+// Collapses the binary tree into 4-wide nodes in depth-first pre-order.  Two passes, both spread
+// over threads near the top of the tree: the first counts the 4-wide nodes below every binary node
+// that becomes one (so that the second knows where each subtree goes), the second writes them.
 struct Collapser {
   const Node2* in;
-  std::vector<BvhNode> out;
-  uint32_t max_depth = 0;
+  uint32_t* below = nullptr;   // per binary node: 4-wide nodes in the subtree it roots (0 if it is adopted away)
+  BvhNode* out = nullptr;
+  std::atomic<uint32_t> max_depth{0};
+  std::atomic<int> free_threads{0};
 
   struct Child {
     Box box;
@@ -232,10 +245,8 @@ struct Collapser {
     r->ref = n.right; r->inner = n.rcount == 0 && n.right >= 0;
   }
 
-  // Emits the 4-wide node for binary node `old_i`; returns its index in `out`.
-  uint32_t emit(uint32_t old_i, uint32_t depth) {
-    max_depth = std::max(max_depth, depth);
-    Child c[4];
+  // The up to four children of the 4-wide node that binary node `old_i` becomes.
+  int gather(uint32_t old_i, Child* c) const {
     int n = 2;
     children_of(in[old_i], &c[0], &c[1]);
     // an absent right child (single-leaf scene) has an inverted box: drop it
@@ -251,8 +262,49 @@ struct Collapser {
       c[best] = l;
       c[n++] = r;
     }
-    const uint32_t me = (uint32_t)out.size();
-    out.emplace_back();
+    return n;
+  }
+
+  // Runs fn(i) for the inner children, the first ones on threads of their own while any are free
+  // and the tree is still shallow enough for the subtrees to be worth it.
+  template <class Fn>
+  void for_inner_children(const Child* c, int n, uint32_t depth, Fn fn) {
+    std::thread workers[4];
+    int n_workers = 0;
+    int last_inner = -1;
+    for (int i = 0; i < n; ++i)
+      if (c[i].inner) last_inner = i;
+    for (int i = 0; i < n; ++i) {
+      if (!c[i].inner) continue;
+      if (i != last_inner && depth <= 6 && free_threads.fetch_sub(1, std::memory_order_relaxed) > 0) {
+        workers[n_workers++] = std::thread([=]() { fn(i); });
+      } else {
+        if (i != last_inner && depth <= 6) free_threads.fetch_add(1, std::memory_order_relaxed);
+        fn(i);
+      }
+    }
+    for (int w = 0; w < n_workers; ++w) {
+      workers[w].join();
+      free_threads.fetch_add(1, std::memory_order_relaxed);
+    }
+  }
+
+  uint32_t count(uint32_t old_i, uint32_t depth) {
+    Child c[4];
+    const int n = gather(old_i, c);
+    uint32_t sizes[4] = {0, 0, 0, 0};
+    for_inner_children(c, n, depth, [&](int i) { sizes[i] = count((uint32_t)c[i].ref, depth + 1); });
+    const uint32_t total = 1 + sizes[0] + sizes[1] + sizes[2] + sizes[3];
+    below[old_i] = total;
+    return total;
+  }
+
+  // Writes the 4-wide node for binary node `old_i` at out[me], its subtrees behind it.
+  void emit(uint32_t old_i, uint32_t me, uint32_t depth) {
+    uint32_t d = max_depth.load(std::memory_order_relaxed);
+    while (depth > d && !max_depth.compare_exchange_weak(d, depth, std::memory_order_relaxed)) {}
+    Child c[4];
+    const int n = gather(old_i, c);
     BvhNode node;
     std::memset(&node, 0, sizeof(node));
     // the node's own box, and per axis the smallest power-of-two grid step that spans it in 255 steps
@@ -276,6 +328,8 @@ struct Collapser {
       node.exp[k] = (uint8_t)(e + 127);
       step[k] = std::ldexp(1.0, e);
     }
+    uint32_t at[4] = {0, 0, 0, 0};
+    uint32_t next = me + 1;
     for (int i = 0; i < 4; ++i) {
       if (i < n && !empty) {
         for (int k = 0; k < 3; ++k) {
@@ -285,18 +339,21 @@ struct Collapser {
           node.qlo[k][i] = (uint8_t)std::min(std::max(lo, 0.0), 255.0);
           node.qhi[k][i] = (uint8_t)std::min(std::max(hi, 0.0), 255.0);
         }
-        node.child[i] = c[i].ref;  // inner references are patched below
+        node.child[i] = c[i].ref;
+        if (c[i].inner) {
+          at[i] = next;
+          node.child[i] = (int32_t)next;
+          next += below[c[i].ref];
+        }
       } else {
         for (int k = 0; k < 3; ++k) { node.qlo[k][i] = 255; node.qhi[k][i] = 0; }
         node.child[i] = ~0;  // replaced by child 0's link below (stays as it is in a scene without triangles, which is never traversed)
       }
     }
-    for (int i = 0; i < n; ++i)
-      if (c[i].inner) node.child[i] = (int32_t)emit((uint32_t)c[i].ref, depth + 1);
     if (!empty)
       for (int i = n; i < 4; ++i) node.child[i] = node.child[0];
     out[me] = node;
-    return me;
+    for_inner_children(c, empty ? 0 : n, depth, [&](int i) { emit((uint32_t)c[i].ref, at[i], depth + 1); });
   }
 };
 
@@ -330,10 +387,16 @@ bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuild
     if (threads > 64) threads = 64;
     b.free_threads = (int)threads - 1;
     for (uint32_t i = 0; i < n_tris; ++i) order[i] = i;
+    const auto t0 = std::chrono::steady_clock::now();
     b.prepare();
+    const auto t1 = std::chrono::steady_clock::now();
     int32_t child, count;
     Box box;
     b.build(0, n_tris, 0, &child, &count, &box);
+    if (std::getenv("RRT_BVH_TIMING"))
+      std::fprintf(stderr, "bvh build: %u triangles, %u threads: bounds %.2f s, binary tree %.2f s\n", n_tris, threads,
+                   std::chrono::duration<double>(t1 - t0).count(),
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     if (count > 0) {  // the whole scene is one leaf: wrap it in a root node
       Node2 root;
       std::memset(&root, 0, sizeof(root));
@@ -347,23 +410,33 @@ bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuild
     }
   }
   // the root of a multi-node binary tree is whichever node the top-level call allocated: index 0
+  const auto t_collapse = std::chrono::steady_clock::now();
   Collapser col;
   col.in = scratch;
-  try {
-    col.emit(0, 1);
-  } catch (const std::bad_alloc&) {
-    std::free(scratch);
-    std::free(order);
-    return false;
-  }
-  std::free(scratch);
-  const uint32_t n_nodes = (uint32_t)col.out.size();
+  col.below = (uint32_t*)std::calloc(cap, sizeof(uint32_t));
+  if (!col.below) { std::free(scratch); std::free(order); return false; }
+  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  if (threads > 64) threads = 64;
+  col.free_threads = (int)threads - 1;
   BvhNode* nodes = nullptr;
-  if (posix_memalign((void**)&nodes, alignof(BvhNode), sizeof(BvhNode) * (size_t)n_nodes) != 0) {
-    std::free(order);
-    return false;
+  uint32_t n_nodes = 0;
+  bool ok = true;
+  try {
+    n_nodes = col.count(0, 1);
+    ok = posix_memalign((void**)&nodes, alignof(BvhNode), sizeof(BvhNode) * (size_t)n_nodes) == 0;
+    if (ok) {
+      col.out = nodes;
+      col.emit(0, 0, 1);
+    }
+  } catch (const std::exception&) {  // thread creation can fail
+    ok = false;
   }
-  std::memcpy(nodes, col.out.data(), sizeof(BvhNode) * (size_t)n_nodes);
+  std::free(col.below);
+  std::free(scratch);
+  if (!ok) { std::free(nodes); std::free(order); return false; }
+  if (std::getenv("RRT_BVH_TIMING"))
+    std::fprintf(stderr, "bvh build: collapse to %u 4-wide nodes %.2f s\n", n_nodes,
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_collapse).count());
   out->nodes = nodes;
   out->n_nodes = n_nodes;
   out->order = order;

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rrt.h"
@@ -158,6 +159,24 @@ int dev_alloc(rrt_ctx* ctx, T** out, size_t count) {
   if (e != hipSuccess) return fail(ctx, RRT_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
   *out = (T*)p;
   return RRT_OK;
+}
+
+// fn(i) for i in [0, n), in contiguous ranges on up to 32 host threads (small n: on this one).
+template <class Fn>
+void parallel_for(uint32_t n, Fn fn) {
+  const uint32_t workers = n < (1u << 18) ? 1u : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  if (workers == 1) {
+    for (uint32_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const uint64_t per = ((uint64_t)n + workers - 1) / workers;
+  for (uint32_t w = 0; w < workers; ++w) {
+    const uint64_t lo = per * w, hi = std::min<uint64_t>(n, lo + per);
+    if (lo >= hi) break;
+    pool.emplace_back([=]() { for (uint64_t i = lo; i < hi; ++i) fn((uint32_t)i); });
+  }
+  for (std::thread& t : pool) t.join();
 }
 
 template <typename T>
@@ -536,9 +555,18 @@ int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   // ---- BVH over the triangles, then the leaf-ordered records
   BvhBuildResult bvh;
   if (!build_bvh(sd->tri_pos, sd->n_tris, 0, &bvh)) return fail(ctx, RRT_E_NOMEM, "BVH build: out of host memory");
-  std::vector<TriIsect> tris(sd->n_tris);
-  std::vector<TriShade> shade(sd->n_tris);
-  for (uint32_t slot = 0; slot < sd->n_tris; ++slot) {
+  // (malloc'ed, not vectors: 100 bytes per triangle that need no zeroing first)
+  TriIsect* tris = (TriIsect*)std::malloc(sizeof(TriIsect) * std::max<size_t>(sd->n_tris, 1));
+  TriShade* shade = (TriShade*)std::malloc(sizeof(TriShade) * std::max<size_t>(sd->n_tris, 1));
+  struct HostRecords {
+    TriIsect* a; TriShade* b;
+    ~HostRecords() { std::free(a); std::free(b); }
+  } host_records{tris, shade};
+  if (!tris || !shade) {
+    free_bvh(&bvh);
+    return fail(ctx, RRT_E_NOMEM, "triangle records: out of host memory");
+  }
+  parallel_for(sd->n_tris, [&](uint32_t slot) {
     const uint32_t id = bvh.order[slot];
     const float* p = sd->tri_pos + (size_t)id * 9;
     const float* n = sd->tri_nrm + (size_t)id * 9;
@@ -555,7 +583,7 @@ int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* sd) {
     shade[slot].n0 = float4{n[0], n[1], n[2], matf};
     shade[slot].n1 = float4{n[3], n[4], n[5], 0.0f};
     shade[slot].n2 = float4{n[6], n[7], n[8], 0.0f};
-  }
+  });
 
   // ---- small tables
   SceneTables& st = ctx->h_scene;
@@ -661,8 +689,8 @@ int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   if (rc == RRT_OK && st.has_env) rc = dev_alloc(ctx, &ctx->d_env, (size_t)sd->env_w * sd->env_h * 3);
   if (rc != RRT_OK) { free_bvh(&bvh); free_scene(ctx); return rc; }
   hipError_t e = hipMemcpy(ctx->d_nodes, bvh.nodes, sizeof(BvhNode) * (size_t)bvh.n_nodes, hipMemcpyHostToDevice);
-  if (e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tris, tris.data(), sizeof(TriIsect) * tris.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tri_shade, shade.data(), sizeof(TriShade) * shade.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tris, tris, sizeof(TriIsect) * (size_t)sd->n_tris, hipMemcpyHostToDevice);
+  if (e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tri_shade, shade, sizeof(TriShade) * (size_t)sd->n_tris, hipMemcpyHostToDevice);
   if (e == hipSuccess && sd->n_materials) e = hipMemcpy(ctx->d_materials, mats.data(), sizeof(DeviceMaterial) * mats.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(ctx->d_scene, &st, sizeof(st), hipMemcpyHostToDevice);
   if (e == hipSuccess && st.has_env) e = hipMemcpy(ctx->d_env, sd->env_rgb8, (size_t)sd->env_w * sd->env_h * 3, hipMemcpyHostToDevice);
