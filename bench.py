@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--batch-samples", type=int, default=0)
     ap.add_argument("--max-slots", type=int, default=0, help="paths in flight (0 = library default: sized from free device memory)")
     ap.add_argument("--no-calibrate", action="store_true")
-    ap.add_argument("--workload", choices=["buddha", "stress"], default="buddha",
+    ap.add_argument("--workload", choices=["buddha", "stress", "cornell", "cornell-matte"], default="buddha",
                     help="buddha: the headline configuration; stress: cow/lamp/teapot trios on a grid (depth 16)")
     ap.add_argument("--trios", type=int, default=3200, help="stress workload: number of trios (15,632 triangles each)")
     args = ap.parse_args()
@@ -145,6 +145,22 @@ def main():
         rs = None
         if rank == 0:
             print("stress scene generated in %.1f s" % (time.perf_counter() - t_gen), file=sys.stderr, flush=True)
+    elif args.workload.startswith("cornell"):
+        # scene/cornell at the frame size and sample count of the second configuration (--spp 1024); "-matte": every
+        # material replaced by Matte with its Kd (the "matte + area light" reading), else the materials as shipped
+        folder = os.path.join(rr.SCENES, "cornell")
+        rs = rr.load_render_settings(folder)
+        scene = rr.Scene.load_from_folder(folder)
+        if args.workload == "cornell-matte":
+            d = scene.desc()
+            for i in range(d.n_materials):
+                m = d.materials[i]
+                scene.set_material(i, rr.make_material(rr.MAT_MATTE, kd=tuple(m.kd), roughness=0.0))
+        camera = rr.Camera.from_settings(rs, W, H)
+        mesh = "cornell.obj"
+        depth_limit, clamp = rs.depth_limit, rs.clamp
+        workload = "scene/cornell %dx%d, %d spp per GPU, depth %d, clamp %g, %s, area light" % (
+            W, H, SPP, depth_limit, clamp, "all materials matte" if args.workload == "cornell-matte" else "materials as shipped")
     else:
         scene, rs, camera, mesh = load_buddha(W, H)
         depth_limit, clamp = rs.depth_limit, rs.clamp
