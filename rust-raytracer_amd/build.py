@@ -32,8 +32,9 @@ def _newer(target, deps):
 # Floating point: no contraction the source does not spell out (the same ray must round the same way in
 # every kernel that traces it; the fused operations that matter are written as fmaf), and hardware
 # reciprocal / square root (1 ulp) instead of the correctly rounded sequences, which were a fifth of
-# the shading kernel's instructions.
-HIP_FP_FLAGS = ["-ffp-contract=off", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+# the shading kernel's instructions; f32 denormals flush to zero, without which every one of those
+# reciprocals and roots is wrapped in a frexp / ldexp rescaling (another fifth).
+HIP_FP_FLAGS = ["-ffp-contract=off", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero"]
 
 
 def _run(cmd, cwd):
