@@ -439,6 +439,30 @@ def test_rounds_of_one_sample_per_slot(rrt, cornell, gpu_ctx):
         assert rel <= 1e-5, name
 
 
+def test_side_stream_changes_nothing(rrt, buddha, gpu_ctx):
+    """Visibility rays on a stream of their own beside the next iteration's closest-hit rays (the default)
+    against everything on one stream: the kernels touch disjoint records, so the films are identical."""
+    scene, rs = buddha
+    w, h, spp = 480, 270, 16
+    cam = rrt.Camera.from_settings(rs, w, h)
+    s = rrt.make_settings(w, h, rs.depth_limit, rs.clamp, seed=3)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    films = []
+    try:
+        for side in (1, 0, 1):
+            gpu_ctx.set_option(rrt.OPT_SIDE_STREAM, side)
+            gpu_ctx.film_clear()
+            gpu_ctx.render(s, 0, spp)
+            films.append(gpu_ctx.film_download())
+    finally:
+        gpu_ctx.set_option(rrt.OPT_SIDE_STREAM, 1)
+    assert films[0][..., :3].max() > 0
+    np.testing.assert_array_equal(films[0], films[1])
+    np.testing.assert_array_equal(films[0], films[2])
+
+
 def test_cpp_host_render(rrt, cornell, gpu_ctx, tmp_path):
     """The C++ host (Scene::load_from_folder, RenderSettingsFile, Camera, render() with its worker
     thread and ThreadMessage channel, Film::merge_accumulators, tone map, PPM / PFM writers) drives
