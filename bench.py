@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: camera-path samples/s of the path-tracing hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+Workload (the configuration the headline metric is quoted on):
 scene/buddha at 1920x1080, 256 samples per pixel, depth 12, clamp 10, aperture 0.1, the scene's
 three area lights + distant light + environment map with MIS, a ~1.09 M-triangle mesh with the
 microfacet plastic material (Kd .6 / Ks 1 / Pr 0.27 / Ni 1.5).  The Happy Buddha OBJ is not part of
