@@ -64,8 +64,12 @@ int rrth_camera_generate_ray(const double position[3], const double target[3], d
 /* Film tone map (src/film.rs:233-249): accumulators float[h][w][4] -> sRGB u8 [h][w][3]. */
 int rrth_tonemap(const float* sum_rgbw, uint32_t width, uint32_t height, uint8_t* rgb8);
 
+/* Image output (the reference has none: it only shows a window): 8-bit RGB rows, top to bottom,
+ * as a PNG whose image data is stored, not compressed. */
+int rrth_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+
 /* main() without the window: load `folder`, render it on the given devices
- * with render() and write <out_prefix>.ppm / .pfm.  samples <= 0 keeps the
+ * with render() and write <out_prefix>.ppm / .png / .pfm.  samples <= 0 keeps the
  * file's max_samples.  Returns camera paths per second through *samples_per_sec. */
 int rrth_render_folder(const char* folder, const int* devices, int n_devices, uint64_t seed, int samples,
                        const char* out_prefix, double* samples_per_sec);

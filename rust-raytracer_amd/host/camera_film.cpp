@@ -1,4 +1,5 @@
 // Camera (src/camera.rs) and Film (src/film.rs) on the host.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -279,6 +280,92 @@ bool Film::write_ppm(const std::string& path) const {
   if (!f) return false;
   std::fprintf(f, "P6\n%u %u\n255\n", width_, height_);
   const bool ok = std::fwrite(image_buffer.data(), 1, image_buffer.size(), f) == image_buffer.size();
+  std::fclose(f);
+  return ok;
+}
+
+namespace {
+
+uint32_t crc32_update(uint32_t crc, const uint8_t* data, size_t n) {
+  static uint32_t table[256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    ready = true;
+  }
+  for (size_t i = 0; i < n; ++i) crc = table[(crc ^ data[i]) & 0xffu] ^ (crc >> 8);
+  return crc;
+}
+
+void put_be32(std::vector<uint8_t>* out, uint32_t v) {
+  for (int s = 24; s >= 0; s -= 8) out->push_back((uint8_t)(v >> s));
+}
+
+bool write_chunk(FILE* f, const char type[4], const std::vector<uint8_t>& body) {
+  std::vector<uint8_t> head;
+  put_be32(&head, (uint32_t)body.size());
+  head.insert(head.end(), type, type + 4);
+  uint32_t crc = crc32_update(0xffffffffu, head.data() + 4, 4);
+  crc = crc32_update(crc, body.data(), body.size()) ^ 0xffffffffu;
+  std::vector<uint8_t> tail;
+  put_be32(&tail, crc);
+  return std::fwrite(head.data(), 1, head.size(), f) == head.size() &&
+         (body.empty() || std::fwrite(body.data(), 1, body.size(), f) == body.size()) &&
+         std::fwrite(tail.data(), 1, tail.size(), f) == tail.size();
+}
+
+}  // namespace
+
+// 8-bit RGB PNG.  The image data goes into stored (uncompressed) deflate blocks: a valid PNG that
+// every reader opens, without a compressor in the host library.
+bool Film::write_png(const std::string& path) const { return write_png_rgb8(path, image_buffer.data(), width_, height_); }
+
+bool write_png_rgb8(const std::string& path, const uint8_t* rgb, uint32_t width_, uint32_t height_) {
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) return false;
+  static const uint8_t signature[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+  bool ok = std::fwrite(signature, 1, 8, f) == 8;
+  std::vector<uint8_t> ihdr;
+  put_be32(&ihdr, width_);
+  put_be32(&ihdr, height_);
+  const uint8_t fmt[5] = {8, 2, 0, 0, 0};  // 8 bits, RGB, deflate, no filter method, no interlace
+  ihdr.insert(ihdr.end(), fmt, fmt + 5);
+  ok = ok && write_chunk(f, "IHDR", ihdr);
+  // scanlines, each led by filter type 0
+  std::vector<uint8_t> raw;
+  raw.reserve(((size_t)width_ * 3 + 1) * height_);
+  for (uint32_t y = 0; y < height_; ++y) {
+    raw.push_back(0);
+    const uint8_t* row = rgb + (size_t)y * width_ * 3;
+    raw.insert(raw.end(), row, row + (size_t)width_ * 3);
+  }
+  uint32_t a = 1, b = 0;  // Adler-32 of the raw data
+  for (uint8_t v : raw) {
+    a = (a + v) % 65521u;
+    b = (b + a) % 65521u;
+  }
+  std::vector<uint8_t> z;
+  z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+  z.push_back(0x78);
+  z.push_back(0x01);
+  size_t at = 0;
+  do {
+    const size_t n = std::min<size_t>(65535, raw.size() - at);
+    z.push_back(at + n == raw.size() ? 1 : 0);  // last block?
+    z.push_back((uint8_t)(n & 0xff));
+    z.push_back((uint8_t)(n >> 8));
+    z.push_back((uint8_t)(~n & 0xff));
+    z.push_back((uint8_t)((~n >> 8) & 0xff));
+    z.insert(z.end(), raw.begin() + (std::ptrdiff_t)at, raw.begin() + (std::ptrdiff_t)(at + n));
+    at += n;
+  } while (at < raw.size());
+  put_be32(&z, (b << 16) | a);
+  ok = ok && write_chunk(f, "IDAT", z);
+  ok = ok && write_chunk(f, "IEND", std::vector<uint8_t>());
   std::fclose(f);
   return ok;
 }

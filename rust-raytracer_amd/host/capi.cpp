@@ -176,8 +176,16 @@ int rrth_render_folder(const char* folder, const int* devices, int n_devices, ui
     if (samples_per_sec) *samples_per_sec = (double)(x1 - x0) * (y1 - y0) * rs.settings.max_samples / secs;
     if (out_prefix) {
       film->write_ppm(std::string(out_prefix) + ".ppm");
+      film->write_png(std::string(out_prefix) + ".png");
       film->write_pfm(std::string(out_prefix) + ".pfm");
     }
+  });
+}
+
+int rrth_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+  return guarded([&] {
+    if (!path || !rgb8 || !width || !height) throw std::runtime_error("bad argument");
+    if (!write_png_rgb8(path, rgb8, width, height)) throw std::runtime_error(std::string("cannot write ") + path);
   });
 }
 

@@ -57,6 +57,9 @@ struct Pixel {
 // src/film.rs:54-251.  Buckets are the CPU scheduler's unit of work and are
 // not needed when a GPU renders whole sample ranges; what remains is the
 // accumulator, the tone map and the 8-bit image.
+// 8-bit RGB rows, top to bottom, as a PNG with stored (uncompressed) image data.
+bool write_png_rgb8(const std::string& path, const uint8_t* rgb, uint32_t width, uint32_t height);
+
 class Film {
  public:
   Film(uint32_t width, uint32_t height, uint32_t bucket_w, uint32_t bucket_h, bool has_crop, uint32_t crop_x0,
@@ -80,6 +83,7 @@ class Film {
   std::vector<uint8_t> image_buffer;  // [h][w][3] sRGB
 
   bool write_ppm(const std::string& path) const;   // 8-bit image
+  bool write_png(const std::string& path) const;   // the same image as PNG (stored, not compressed)
   bool write_pfm(const std::string& path) const;   // linear sum_radiance / sum_weight
 
  private:

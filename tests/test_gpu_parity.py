@@ -481,6 +481,8 @@ def test_cpp_host_render(rrt, cornell, gpu_ctx, tmp_path):
     with open(prefix + ".ppm", "rb") as f:
         assert f.readline() == b"P6\n" and f.readline() == b"%d %d\n" % (w, h) and f.readline() == b"255\n"
         ppm = np.frombuffer(f.read(), dtype=np.uint8).reshape(h, w, 3)
+    from test_host_and_abi import _read_png
+    np.testing.assert_array_equal(_read_png(prefix + ".png"), ppm)
     with open(prefix + ".pfm", "rb") as f:
         assert f.readline() == b"PF\n" and f.readline() == b"%d %d\n" % (w, h) and f.readline() == b"-1.0\n"
         pfm = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)[::-1]

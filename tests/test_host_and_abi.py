@@ -88,6 +88,38 @@ def test_hierarchy_invariants(rrt):
             assert n_nodes < len(tris) and depth < 64, (name, n_nodes, depth)
 
 
+def _read_png(path):
+    """Decodes an 8-bit RGB, filter-0 PNG with the standard library (checks every chunk's CRC)."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, chunks = 8, []
+    while at < len(data):
+        n, kind = struct.unpack(">I4s", data[at:at + 8])
+        body = data[at + 8:at + 8 + n]
+        assert struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + body)
+        chunks.append((kind, body))
+        at += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, colour, comp, filt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, colour, comp, filt, lace) == (8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(h, 1 + 3 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+def test_png_writer(rrt, tmp_path):
+    """Sizes that fit one stored block, need several (> 65535 bytes), and a single pixel."""
+    rng = np.random.default_rng(9)
+    for w, h in ((1, 1), (37, 21), (320, 200)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        path = str(tmp_path / ("t%dx%d.png" % (w, h)))
+        assert rrt.host_lib().rrth_write_png(os.fsencode(path), img.ctypes.data, w, h) == 0
+        np.testing.assert_array_equal(_read_png(path), img)
+    assert rrt.host_lib().rrth_write_png(os.fsencode(str(tmp_path / "no" / "dir.png")), img.ctypes.data, 4, 4) != 0
+
+
 def test_fast_division_formula():
     """The kernels divide slot and tile numbers (< 2^30) by run-time constants as
     (mulhi(m, x) + x) >> l with l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1 (csrc/rrt_kernels.h,
