@@ -217,7 +217,7 @@ int rrt_synchronize(rrt_ctx* ctx);
 /* Sums the film accumulators of n contexts (one per GPU, one process) into
  * ctxs[root] with RCCL.  Multi-process callers reduce the bound film buffer
  * with their own communicator instead. */
-int rrt_film_reduce(rrt_ctx** ctxs, int n, int root);
+int rrt_film_reduce(rrt_ctx** ctxs, int n, int root);  /* (and the first-hit buffers, if every context keeps them) */
 
 /* check_intersect_scene (src/renderer.rs:213-249) for n rays given as host
  * [n][6] = origin xyz, direction xyz: object id of the closest hit (-1 = miss)
@@ -237,6 +237,17 @@ int rrt_occluded(rrt_ctx* ctx, const float* org_dir_tmax, uint32_t n, uint8_t* h
  * Has no counterpart in the reference (its hierarchy is the bvh crate's): a self-check. */
 int64_t rrt_bvh_selfcheck(const float* tri_pos, uint32_t n_tris, uint32_t* n_nodes, uint32_t* max_depth);
 
+/* First-hit buffers for a denoiser (the reference's SampleResult carries normal and albedo
+ * but leaves them zero, src/tracer.rs:36-37,65-68; its denoiser reads them from the film,
+ * src/denoise.rs:9-23).  With RRT_OPT_AOVS on, rrt_render also adds, per pixel, the shading
+ * normal and the albedo (diffuse colour, else specular, else transmission colour) of the surface
+ * each camera ray hits; rays that escape add nothing.  host arrays are [height][width][4]:
+ * (sum nx, sum ny, sum nz, number of hits) and (sum r, sum g, sum b, 0); divide by the film's
+ * sum of weights for per-pixel means.  rrt_film_clear clears them too.  rrt_aov_device_ptr: the
+ * two arrays back to back on the device, for hosts that reduce them across GPUs themselves. */
+int rrt_aov_download(rrt_ctx* ctx, float* host_normal_sum, float* host_albedo_sum);
+void* rrt_aov_device_ptr(rrt_ctx* ctx);
+
 /* Options. */
 enum {
   RRT_OPT_TIMING = 1,          /* 1: time each kernel with HIP events (the host waits at the end of every pass) */
@@ -246,6 +257,7 @@ enum {
   RRT_OPT_MAX_SLOTS = 3,       /* upper bound on paths in flight (sizes the path-state arrays; at most 2^30; 0 = 60 % of the
                                   free device memory) */
   RRT_OPT_COUNT_TRAVERSAL = 4, /* 1: count nodes_visited / tris_tested (slower kernels; for calibration runs) */
+  RRT_OPT_AOVS = 6,            /* 1: accumulate first-hit normal and albedo (rrt_aov_download); default 0 */
   RRT_OPT_SIDE_STREAM = 5      /* 1 (default): rrt_render runs the visibility rays of an iteration on a stream of its own
                                   beside the next iteration's closest-hit rays and joins it again before it returns
                                   work to the caller's stream; 0: everything on the one stream (per-kernel times in

@@ -42,6 +42,7 @@ def lib():
         L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_void_p, C.POINTER(OracleStats)]
         L.orc_trace_one.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, dp]
+        L.orc_first_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, dp, dp]
         L.orc_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_intersect_margin.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_occluded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -125,6 +126,23 @@ class Oracle:
         rc = self._lib.orc_trace_one(self._h, C.byref(settings), px, py, sample, out)
         assert rc == 0
         return np.array(out[:])
+
+    def first_hit_sums(self, settings, width, height, sample_begin, sample_end):
+        """Per-pixel sums of orc_first_hit over the samples: (normal [h][w][4] with the hit count in w,
+        albedo [h][w][4])."""
+        normal = np.zeros((height, width, 4))
+        albedo = np.zeros((height, width, 4))
+        n, a = (C.c_double * 3)(), (C.c_double * 3)()
+        for y in range(height):
+            for x in range(width):
+                for s in range(sample_begin, sample_end):
+                    rc = self._lib.orc_first_hit(self._h, C.byref(settings), x, y, s, n, a)
+                    assert rc >= 0
+                    if rc:
+                        normal[y, x, :3] += n[:]
+                        normal[y, x, 3] += 1
+                        albedo[y, x, :3] += a[:]
+        return normal, albedo
 
     def intersect(self, org_dir, with_margin=False):
         rays = np.ascontiguousarray(org_dir, dtype=np.float64).reshape(-1, 6)

@@ -1664,6 +1664,28 @@ int orc_trace_one(orc_ctx* ctx, const rrt_settings* st, uint32_t px, uint32_t py
   return RRT_OK;
 }
 
+// What the device's first-hit buffers hold for one camera sample: the shading normal of the surface
+// the camera ray hits and its albedo (Kd, or Ks for a plastic without a diffuse lobe).  The reference
+// has the two fields but leaves them zero (src/tracer.rs:36-37, 65-68).
+int orc_first_hit(orc_ctx* ctx, const rrt_settings* st, uint32_t px, uint32_t py, uint32_t sample, double normal[3],
+                  double albedo[3]) {
+  if (!ctx || !st || !normal || !albedo || !ctx->camera.set) return RRT_E_INVALID;
+  PathRng rng{st->seed, py * st->width + px, sample};
+  const RngBlock cam = rng.block(0);
+  const Ray ray = generate_ray(ctx->camera, (double)px + cam.u[0], (double)py + cam.u[1], cam.u[2], cam.u[3]);
+  Counters c;
+  SurfaceInteraction si;
+  int obj = -1;
+  double dist = 0;
+  for (int k = 0; k < 3; ++k) normal[k] = albedo[k] = 0.0;
+  if (!check_intersect_scene(*ctx, ray, &c, &si, &obj, &dist)) return 0;
+  normal[0] = si.shading_normal.x; normal[1] = si.shading_normal.y; normal[2] = si.shading_normal.z;
+  const rrt_material& m = ctx->materials[ctx->objects[obj].material];
+  const bool kd_zero = m.kd[0] == 0.0 && m.kd[1] == 0.0 && m.kd[2] == 0.0;
+  for (int k = 0; k < 3; ++k) albedo[k] = (m.kind == RRT_MAT_PLASTIC && kd_zero) ? m.ks[k] : m.kd[k];
+  return 1;
+}
+
 int orc_intersect(orc_ctx* ctx, const double* od, uint32_t n, int32_t* prim_id, double* t) {
   if (!ctx || !od || !prim_id || !t) return RRT_E_INVALID;
   Counters c;

@@ -63,6 +63,11 @@ int orc_render(orc_ctx* ctx, const rrt_settings* settings, uint32_t sample_begin
 int orc_trace_one(orc_ctx* ctx, const rrt_settings* settings, uint32_t px, uint32_t py, uint32_t sample,
                   double out[3]);
 
+/* First hit of camera sample (pixel, sample): shading normal and albedo as the device's first-hit
+ * buffers define them; returns 1 on a hit, 0 on a miss (both outputs zero), < 0 on error. */
+int orc_first_hit(orc_ctx* ctx, const rrt_settings* settings, uint32_t px, uint32_t py, uint32_t sample,
+                  double normal[3], double albedo[3]);
+
 /* check_intersect_scene / check_intersect_scene_simple on explicit rays. */
 int orc_intersect(orc_ctx* ctx, const double* org_dir, uint32_t n, int32_t* prim_id, double* t);
 int orc_occluded(orc_ctx* ctx, const double* org_dir_tmax, uint32_t n, uint8_t* hit);

@@ -91,7 +91,7 @@ class RenderSettingsFile(C.Structure):
 MAT_MATTE, MAT_PLASTIC, MAT_MIRROR, MAT_GLASS = 0, 1, 2, 3
 LIGHT_POINT, LIGHT_AREA, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2, 3
 RECT_AABB_STRICT, RECT_AABB_INCLUSIVE, RECT_AABB_OFF = 0, 1, 2
-OPT_TIMING, OPT_BATCH_SAMPLES, OPT_MAX_SLOTS, OPT_COUNT_TRAVERSAL, OPT_SIDE_STREAM = 1, 2, 3, 4, 5
+OPT_TIMING, OPT_BATCH_SAMPLES, OPT_MAX_SLOTS, OPT_COUNT_TRAVERSAL, OPT_SIDE_STREAM, OPT_AOVS = 1, 2, 3, 4, 5, 6
 FILTER_NONE, FILTER_GAUSSIAN, FILTER_MITCHELL = 0, 1, 2
 
 # every symbol include/rrt.h and include/rrt_host.h declare
@@ -99,7 +99,7 @@ RRT_SYMBOLS = ["rrt_device_count", "rrt_create", "rrt_destroy", "rrt_set_stream"
                "rrt_set_camera", "rrt_film_alloc", "rrt_film_bind", "rrt_film_clear", "rrt_film_download",
                "rrt_film_device_ptr", "rrt_render", "rrt_synchronize", "rrt_film_reduce", "rrt_intersect",
                "rrt_occluded", "rrt_set_option", "rrt_get_stats", "rrt_reset_stats", "rrt_last_error",
-               "rrt_set_filter", "rrt_film_tonemap", "rrt_bvh_selfcheck"]
+               "rrt_set_filter", "rrt_film_tonemap", "rrt_bvh_selfcheck", "rrt_aov_download", "rrt_aov_device_ptr"]
 RRTH_SYMBOLS = ["rrth_last_error", "rrth_scene_load", "rrth_scene_load_with_mesh", "rrth_scene_free",
                 "rrth_scene_desc", "rrth_scene_set_rect_aabb_mode", "rrth_scene_set_material",
                 "rrth_load_render_settings", "rrth_camera_matrices", "rrth_camera_generate_ray", "rrth_tonemap",
@@ -133,6 +133,9 @@ def hip_lib():
         lib.rrt_film_device_ptr.restype = C.c_void_p
         lib.rrt_set_filter.argtypes = [C.c_void_p, C.c_uint32, C.c_double]
         lib.rrt_film_tonemap.argtypes = [C.c_void_p, C.c_void_p]
+        lib.rrt_aov_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rrt_aov_device_ptr.argtypes = [C.c_void_p]
+        lib.rrt_aov_device_ptr.restype = C.c_void_p
         lib.rrt_render.argtypes = [C.c_void_p, C.POINTER(Settings), C.c_uint32, C.c_uint32]
         lib.rrt_synchronize.argtypes = [C.c_void_p]
         lib.rrt_film_reduce.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
@@ -460,6 +463,13 @@ class Context:
         out = np.empty(self._film_shape[:2] + (3,), dtype=np.uint8)
         self._check(self._lib.rrt_film_tonemap(self._h, out.ctypes.data), "rrt_film_tonemap")
         return out
+
+    def aov_download(self):
+        """First-hit sums (OPT_AOVS): normal [h][w][4] = (sum n, hits), albedo [h][w][4] = (sum rgb, 0)."""
+        normal = np.empty(self._film_shape[:2] + (4,), dtype=np.float32)
+        albedo = np.empty_like(normal)
+        self._check(self._lib.rrt_aov_download(self._h, normal.ctypes.data, albedo.ctypes.data), "rrt_aov_download")
+        return normal, albedo
 
     def render(self, settings, sample_begin, sample_end):
         self._check(self._lib.rrt_render(self._h, C.byref(settings), sample_begin, sample_end), "rrt_render")

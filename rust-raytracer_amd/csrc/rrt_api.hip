@@ -98,6 +98,9 @@ struct rrt_ctx {
   bool timing = false;
   bool count_traversal = false;
   bool side_stream_allowed = true;            // RRT_OPT_SIDE_STREAM
+  bool aovs = false;                          // RRT_OPT_AOVS
+  float* d_aov = nullptr;                     // [2][film_h][film_w][4]: first-hit normal sums (+ hit count), albedo sums
+  uint32_t aov_w = 0, aov_h = 0;
   uint32_t batch_samples = 0;
   uint32_t max_slots = 0;  // 0: sized from the free device memory
 
@@ -505,6 +508,7 @@ void rrt_destroy(rrt_ctx* ctx) {
   (void)hipFree(ctx->d_stats);
   (void)hipFree(ctx->d_work);
   (void)hipFree(ctx->d_filter_table);
+  (void)hipFree(ctx->d_aov);
   if (ctx->h_pending) (void)hipHostFree(ctx->h_pending);
   for (EventPair& e : ctx->events) {
     (void)hipEventDestroy(e.begin);
@@ -717,6 +721,23 @@ int rrt_set_camera(rrt_ctx* ctx, const double raster_to_camera[16], const double
   return RRT_OK;
 }
 
+namespace {
+size_t aov_bytes(const rrt_ctx* ctx) { return sizeof(float) * 8 * (size_t)ctx->aov_w * ctx->aov_h; }
+
+// The first-hit buffers follow the film's size; allocated (and zeroed) on first need.
+int ensure_aov(rrt_ctx* ctx) {
+  if (ctx->d_aov && ctx->aov_w == ctx->film_w && ctx->aov_h == ctx->film_h) return RRT_OK;
+  if (ctx->d_aov) (void)hipFree(ctx->d_aov);
+  ctx->d_aov = nullptr;
+  ctx->aov_w = ctx->film_w;
+  ctx->aov_h = ctx->film_h;
+  int rc = dev_alloc(ctx, &ctx->d_aov, (size_t)ctx->aov_w * ctx->aov_h * 8);
+  if (rc != RRT_OK) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_aov, 0, aov_bytes(ctx), ctx->stream));
+  return RRT_OK;
+}
+}  // namespace
+
 int rrt_film_alloc(rrt_ctx* ctx, uint32_t width, uint32_t height) {
   if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
   if (!width || !height) return fail(ctx, RRT_E_INVALID, "empty film");
@@ -754,7 +775,29 @@ int rrt_film_clear(rrt_ctx* ctx) {
   int rc = bind_device(ctx);
   if (rc != RRT_OK) return rc;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_film, 0, sizeof(float) * 4 * (size_t)ctx->film_w * ctx->film_h, ctx->stream));
+  if (ctx->d_aov && ctx->aov_w == ctx->film_w && ctx->aov_h == ctx->film_h)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_aov, 0, aov_bytes(ctx), ctx->stream));
   return RRT_OK;
+}
+
+int rrt_aov_download(rrt_ctx* ctx, float* host_normal_sum, float* host_albedo_sum) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!host_normal_sum || !host_albedo_sum) return fail(ctx, RRT_E_INVALID, "null destination");
+  if (!ctx->d_film) return fail(ctx, RRT_E_STATE, "no film");
+  if (!ctx->aovs) return fail(ctx, RRT_E_STATE, "RRT_OPT_AOVS is off");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  if ((rc = ensure_aov(ctx)) != RRT_OK) return rc;
+  const size_t half = aov_bytes(ctx) / 2;
+  HIP_TRY(ctx, hipMemcpyAsync(host_normal_sum, ctx->d_aov, half, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(host_albedo_sum, (const char*)ctx->d_aov + half, half, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return RRT_OK;
+}
+
+void* rrt_aov_device_ptr(rrt_ctx* ctx) {
+  if (!ctx || !ctx->aovs || !ctx->d_film || bind_device(ctx) != RRT_OK || ensure_aov(ctx) != RRT_OK) return nullptr;
+  return ctx->d_aov;
 }
 
 int rrt_film_download(rrt_ctx* ctx, float* host) {
@@ -917,6 +960,11 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
   p.env = ctx->d_env;
   p.stats = ctx->d_stats;
   p.film = ctx->d_film;
+  p.aov = nullptr;
+  if (ctx->aovs) {
+    if ((rc = ensure_aov(ctx)) != RRT_OK) return rc;
+    p.aov = ctx->d_aov;
+  }
   p.seed = s->seed;
   p.width = s->width;
   p.height = s->height;
@@ -1040,6 +1088,7 @@ int rrt_set_option(rrt_ctx* ctx, int option, int64_t value) {
       return RRT_OK;
     case RRT_OPT_COUNT_TRAVERSAL: ctx->count_traversal = value != 0; return RRT_OK;
     case RRT_OPT_SIDE_STREAM: ctx->side_stream_allowed = value != 0; return RRT_OK;
+    case RRT_OPT_AOVS: ctx->aovs = value != 0; return RRT_OK;
     default: return fail(ctx, RRT_E_INVALID, "unknown option");
   }
 }
@@ -1155,6 +1204,18 @@ int rrt_film_reduce(rrt_ctx** ctxs, int n, int root) {
     if (reduce(ctxs[i]->d_film, ctxs[i]->d_film, count, 7, 0, root, comms[i], ctxs[i]->stream) != 0) rc = RRT_E_DEVICE;
   }
   group_end();
+  // the first-hit buffers as well, when every context keeps them
+  bool all_aovs = true;
+  for (int i = 0; i < n; ++i)
+    all_aovs = all_aovs && ctxs[i]->aovs && ctxs[i]->d_aov && ctxs[i]->aov_w == ctxs[0]->film_w && ctxs[i]->aov_h == ctxs[0]->film_h;
+  if (all_aovs && rc == RRT_OK) {
+    group_start();
+    for (int i = 0; i < n; ++i) {
+      (void)hipSetDevice(ctxs[i]->device);
+      if (reduce(ctxs[i]->d_aov, ctxs[i]->d_aov, 2 * count, 7, 0, root, comms[i], ctxs[i]->stream) != 0) rc = RRT_E_DEVICE;
+    }
+    group_end();
+  }
   for (int i = 0; i < n; ++i) {
     (void)hipSetDevice(ctxs[i]->device);
     (void)hipStreamSynchronize(ctxs[i]->stream);

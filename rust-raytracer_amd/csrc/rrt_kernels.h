@@ -159,6 +159,7 @@ struct RenderParams {
   uint32_t win_x0, win_y0, win_w, win_h;  // render window
   uint32_t tiles_x;                 // 8x8 pixel tiles per window row
   FastDiv div_tiles_x, div_samples; // divisions by tiles_x and n_samples
+  float* aov;                       // first-hit buffers [2][height][width][4] or null
   uint32_t tile_begin, n_tiles;     // tiles of this pass
   uint32_t sample_begin, sample_end;
   uint32_t n_samples;               // K: slots per pixel
@@ -645,6 +646,15 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
                                         : surface_other(sc, prim, h4.y, org, dir);
     const DeviceMaterial m = p.materials[s.material];
     const uint32_t pixel = y * p.width + x;
+    if (p.aov && bounce == 0) {
+      // what a denoiser wants beside the image: the shading normal and the albedo of what the camera sees
+      float* an = p.aov + 4 * (size_t)pixel;
+      float* aa = an + 4 * (size_t)p.width * p.height;
+      const V3 albedo = m.diffuse_kind != DIFF_NONE ? mk(m.diffuse) : (m.spec_kind != SPEC_NONE ? mk(m.spec) : mk(m.trans));
+      unsafeAtomicAdd(an + 0, s.ns.x); unsafeAtomicAdd(an + 1, s.ns.y); unsafeAtomicAdd(an + 2, s.ns.z);
+      unsafeAtomicAdd(an + 3, 1.0f);
+      unsafeAtomicAdd(aa + 0, albedo.x); unsafeAtomicAdd(aa + 1, albedo.y); unsafeAtomicAdd(aa + 2, albedo.z);
+    }
     const Rng4 ra = rng_block(p.seed, pixel, sample, 1 + 3 * bounce);
 
     // ---- uniform_sample_light + estimate_direct (src/tracer.rs:141-283)

@@ -229,6 +229,46 @@ def test_per_path_radiance_mixed(rrt, oracle_binding, mixed, gpu_ctx, depth):
     assert close.mean() >= 0.998
 
 
+def test_first_hit_buffers(rrt, oracle_binding, mixed, gpu_ctx):
+    """RRT_OPT_AOVS: per-pixel sums of the shading normal and the albedo of what the camera rays hit,
+    against the oracle's first hits of the same samples (every shape and material kind, thin lens).
+    Off by default; cleared with the film; a second call adds to them."""
+    scene, rs, _ = mixed
+    w, h, spp = 60, 45, 4
+    cam = rrt.Camera.from_settings(rs, w, h)
+    s = rrt.make_settings(w, h, 3, rs.clamp, seed=5)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    with pytest.raises(rrt.RrtError):
+        gpu_ctx.aov_download()
+    orc = oracle_binding.Oracle(scene.desc())
+    orc.set_camera(cam)
+    ref_n, ref_a = orc.first_hit_sums(s, w, h, 0, spp)
+    try:
+        gpu_ctx.set_option(rrt.OPT_AOVS, 1)
+        gpu_ctx.render(s, 0, 1)
+        gpu_ctx.render(s, 1, spp)
+        film = gpu_ctx.film_download()
+        dev_n, dev_a = gpu_ctx.aov_download()
+        gpu_ctx.film_clear()
+        zero_n, zero_a = gpu_ctx.aov_download()
+    finally:
+        gpu_ctx.set_option(rrt.OPT_AOVS, 0)
+    assert (zero_n == 0).all() and (zero_a == 0).all()
+    assert (film[..., 3] == spp).all()
+    same_hits = dev_n[..., 3] == ref_n[..., 3]
+    print("hit counts agree on %.4f of the pixels; %.3f of the camera rays hit" % (same_hits.mean(), ref_n[..., 3].sum() / (w * h * spp)))
+    assert same_hits.mean() >= 0.995 and ref_n[..., 3].sum() > 0.3 * w * h * spp
+    ok = same_hits
+    np.testing.assert_allclose(dev_a[ok][:, :3], ref_a[ok][:, :3], rtol=1e-5, atol=1e-6)
+    # normals: a ray that hits an edge between two faces may take either; all but a few pixels agree closely
+    close = np.abs(dev_n[ok][:, :3] - ref_n[ok][:, :3]).max(axis=1) <= 2e-3 * spp
+    print("normal sums agree on %.4f of those" % close.mean())
+    assert close.mean() >= 0.99
+    assert len(set(map(tuple, np.round(ref_a[ref_n[..., 3] == spp][:, :3] / spp, 3)))) >= 4  # several materials in view
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_rect_aabb_modes(rrt, oracle_binding, gpu_ctx, mode):
     """The three readings of the reference's box pre-filter for quads agree between device and oracle."""

@@ -134,3 +134,24 @@ def test_oracle_filter_splat(rrt, oracle_binding, cornell, method):
     orc.set_filter(0)
     again, _ = orc.render(s, 0, 1, threads=2)
     np.testing.assert_array_equal(again, plain)
+
+
+def test_oracle_first_hits_are_consistent(rrt, oracle_binding, cornell):
+    """orc_first_hit: unit shading normals facing the camera ray's side of the surface or not (cornell's
+    boxes are closed, seen from outside: facing), albedos out of the scene's material table, and a hit
+    exactly where a depth-1 render finds something to shade."""
+    scene, rs = cornell
+    w, h = 24, 24
+    cam = rrt.Camera.from_settings(rs, w, h)
+    s = rrt.make_settings(w, h, 1, rs.clamp, seed=2)
+    orc = oracle_binding.Oracle(scene.desc())
+    orc.set_camera(cam)
+    normal, albedo = orc.first_hit_sums(s, w, h, 0, 1)
+    hit = normal[..., 3] == 1
+    assert hit.mean() > 0.9  # the room fills the view
+    np.testing.assert_allclose(np.linalg.norm(normal[hit][:, :3], axis=1), 1.0, atol=1e-9)
+    assert (normal[~hit] == 0).all() and (albedo[~hit] == 0).all()
+    d = scene.desc()
+    table = {tuple(np.round(list(d.materials[i].kd), 6)) for i in range(d.n_materials)}
+    seen = {tuple(np.round(a, 6)) for a in albedo[hit][:, :3]}
+    assert seen <= table and len(seen) >= 3
