@@ -73,6 +73,12 @@ int rrth_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32
  * file's max_samples.  Returns camera paths per second through *samples_per_sec. */
 int rrth_render_folder(const char* folder, const int* devices, int n_devices, uint64_t seed, int samples,
                        const char* out_prefix, double* samples_per_sec);
+/* The same, and the two maps the reference's denoise() hands to OIDN (src/denoise.rs:9-23) filled
+ * from the devices' first-hit buffers: float [height][width][3] each, per-pixel means of the shading
+ * normal and the albedo of what the camera rays hit (either may be null). */
+int rrth_render_folder_first_hits(const char* folder, const int* devices, int n_devices, uint64_t seed, int samples,
+                                  const char* out_prefix, double* samples_per_sec, float* normal_map,
+                                  float* albedo_map);
 
 #ifdef __cplusplus
 }

@@ -103,7 +103,7 @@ RRT_SYMBOLS = ["rrt_device_count", "rrt_create", "rrt_destroy", "rrt_set_stream"
 RRTH_SYMBOLS = ["rrth_last_error", "rrth_scene_load", "rrth_scene_load_with_mesh", "rrth_scene_free",
                 "rrth_scene_desc", "rrth_scene_set_rect_aabb_mode", "rrth_scene_set_material",
                 "rrth_load_render_settings", "rrth_camera_matrices", "rrth_camera_generate_ray", "rrth_tonemap",
-                "rrth_render_folder", "rrth_write_png"]
+                "rrth_render_folder", "rrth_write_png", "rrth_render_folder_first_hits"]
 
 _hip = None
 _host = None
@@ -180,6 +180,7 @@ def host_lib():
         lib.rrth_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.rrth_render_folder.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_uint64, C.c_int, C.c_char_p,
                                            C.POINTER(C.c_double)]
+        lib.rrth_render_folder_first_hits.argtypes = lib.rrth_render_folder.argtypes + [C.c_void_p, C.c_void_p]
         _host = lib
     return _host
 

@@ -275,6 +275,27 @@ void Film::merge_accumulators(const float* acc) {
   }
 }
 
+void Film::merge_first_hits(const float* normal_sum, const float* albedo_sum) {
+  for (size_t i = 0; i < pixels.size(); ++i)
+    for (int k = 0; k < 3; ++k) {
+      pixels[i].sum_normal[k] += (double)normal_sum[4 * i + k];
+      pixels[i].sum_albedo[k] += (double)albedo_sum[4 * i + k];
+    }
+}
+
+void Film::first_hit_maps(std::vector<float>* normal_map, std::vector<float>* albedo_map) const {
+  normal_map->assign(pixels.size() * 3, 0.0f);
+  albedo_map->assign(pixels.size() * 3, 0.0f);
+  for (size_t i = 0; i < pixels.size(); ++i) {
+    const Pixel& p = pixels[i];
+    if (!(p.sum_weight > 0.0)) continue;
+    for (int k = 0; k < 3; ++k) {
+      (*normal_map)[3 * i + k] = (float)(p.sum_normal[k] / p.sum_weight);
+      (*albedo_map)[3 * i + k] = (float)(p.sum_albedo[k] / p.sum_weight);
+    }
+  }
+}
+
 bool Film::write_ppm(const std::string& path) const {
   FILE* f = std::fopen(path.c_str(), "wb");
   if (!f) return false;

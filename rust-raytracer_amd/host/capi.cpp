@@ -153,12 +153,20 @@ int rrth_tonemap(const float* sum_rgbw, uint32_t width, uint32_t height, uint8_t
 
 int rrth_render_folder(const char* folder, const int* devices, int n_devices, uint64_t seed, int samples,
                        const char* out_prefix, double* samples_per_sec) {
+  return rrth_render_folder_first_hits(folder, devices, n_devices, seed, samples, out_prefix, samples_per_sec, nullptr,
+                                       nullptr);
+}
+
+int rrth_render_folder_first_hits(const char* folder, const int* devices, int n_devices, uint64_t seed, int samples,
+                                  const char* out_prefix, double* samples_per_sec, float* normal_map,
+                                  float* albedo_map) {
   return guarded([&] {
     if (!folder || !devices || n_devices <= 0) throw std::runtime_error("bad argument");
     auto scene = Scene::load_from_folder(folder);
     RenderSettingsFile rs = RenderSettingsFile::load(folder);
     if (samples > 0) rs.settings.max_samples = (uint32_t)samples;
     auto film = rs.make_film();
+    film->keep_first_hits(normal_map || albedo_map);
     auto camera = rs.make_camera();
     std::vector<int> devs(devices, devices + n_devices);
     const auto t0 = std::chrono::steady_clock::now();
@@ -178,6 +186,12 @@ int rrth_render_folder(const char* folder, const int* devices, int n_devices, ui
       film->write_ppm(std::string(out_prefix) + ".ppm");
       film->write_png(std::string(out_prefix) + ".png");
       film->write_pfm(std::string(out_prefix) + ".pfm");
+    }
+    if (film->keeps_first_hits()) {
+      std::vector<float> n, a;
+      film->first_hit_maps(&n, &a);
+      if (normal_map) std::memcpy(normal_map, n.data(), n.size() * sizeof(float));
+      if (albedo_map) std::memcpy(albedo_map, a.data(), a.size() * sizeof(float));
     }
   });
 }

@@ -80,6 +80,8 @@ std::unique_ptr<RenderJob> render(const Scene& scene, const Settings& settings, 
                                 : film->filter_method() == FilterMethod::Mitchell ? RRT_FILTER_MITCHELL
                                                                                   : RRT_FILTER_NONE;
         check(ctx, rrt_set_filter(ctx, method, film->filter_radius()), "rrt_set_filter");
+        const bool first_hits = film->keeps_first_hits();
+        check(ctx, rrt_set_option(ctx, RRT_OPT_AOVS, first_hits ? 1 : 0), "rrt_set_option");
 
         rrt_settings s{};
         s.width = film->width();
@@ -94,13 +96,16 @@ std::unique_ptr<RenderJob> render(const Scene& scene, const Settings& settings, 
         const uint32_t end = (uint32_t)((uint64_t)settings.max_samples * (g + 1) / n_dev);
         const uint32_t step = samples_per_merge ? samples_per_merge : (end - begin ? end - begin : 1);
         std::vector<float> acc((size_t)film->width() * film->height() * 4);
+        std::vector<float> hit_normal(first_hits ? acc.size() : 0), hit_albedo(first_hits ? acc.size() : 0);
         for (uint32_t b = begin; b < end; b += step) {
           const uint32_t e = b + step < end ? b + step : end;
           check(ctx, rrt_film_clear(ctx), "rrt_film_clear");
           check(ctx, rrt_render(ctx, &s, b, e), "rrt_render");
           check(ctx, rrt_film_download(ctx, acc.data()), "rrt_film_download");
+          if (first_hits) check(ctx, rrt_aov_download(ctx, hit_normal.data(), hit_albedo.data()), "rrt_aov_download");
           std::lock_guard<std::mutex> lock(j->film_mu_);  // film.write() in the reference
           film->merge_accumulators(acc.data());
+          if (first_hits) film->merge_first_hits(hit_normal.data(), hit_albedo.data());
         }
         rrt_stats st{};
         rrt_get_stats(ctx, &st);

@@ -48,10 +48,14 @@ struct Settings {
 enum class FilterMethod { None, Gaussian, Mitchell };
 FilterMethod filter_method_from_str(const std::string& s);
 
-// src/film.rs:46-52 (normal / albedo are always zero in the reference, src/tracer.rs:36-37, and are not kept)
+// src/film.rs:46-52.  normal / albedo: the reference has the two fields and hands them to its
+// denoiser (src/denoise.rs:9-23) but never fills them (src/tracer.rs:36-37); here they hold the sums
+// of the device's first-hit buffers when the film keeps them.
 struct Pixel {
   double sum_weight = 0;
   double sum_radiance[3] = {0, 0, 0};
+  double sum_normal[3] = {0, 0, 0};
+  double sum_albedo[3] = {0, 0, 0};
 };
 
 // src/film.rs:54-251.  Buckets are the CPU scheduler's unit of work and are
@@ -79,6 +83,14 @@ class Film {
   void merge_accumulators(const float* sum_rgbw);
   void clear();
 
+  // First-hit normal and albedo for a denoiser: when on, render() has the devices collect them and
+  // merges them here; first_hit_maps() gives the two float[h][w][3] arrays denoise() builds for OIDN
+  // (src/denoise.rs:9-23), as per-pixel means over the samples.
+  void keep_first_hits(bool on) { keep_first_hits_ = on; }
+  bool keeps_first_hits() const { return keep_first_hits_; }
+  void merge_first_hits(const float* normal_sum, const float* albedo_sum);  // device arrays [h][w][4]
+  void first_hit_maps(std::vector<float>* normal_map, std::vector<float>* albedo_map) const;
+
   std::vector<Pixel> pixels;
   std::vector<uint8_t> image_buffer;  // [h][w][3] sRGB
 
@@ -93,6 +105,7 @@ class Film {
   FilterMethod filter_method_;
   double filter_radius_;
   std::vector<double> filter_table_;  // 16 x 16 (src/film.rs:87-112)
+  bool keep_first_hits_ = false;
 };
 
 // Tone map pieces (src/film.rs:360-406).

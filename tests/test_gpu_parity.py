@@ -535,6 +535,36 @@ def test_cpp_host_render(rrt, cornell, gpu_ctx, tmp_path):
     assert ppm.mean() > 10
 
 
+def test_cpp_host_first_hit_maps(rrt, cornell, gpu_ctx):
+    """The C++ host with a film that keeps first hits: the two maps denoise() would hand to OIDN
+    (src/denoise.rs:9-23), against the device buffers through the ctypes layer with the same seed."""
+    import ctypes as C
+    scene, rs = cornell
+    w, h, spp = rs.image_width, rs.image_height, 2
+    nmap = np.zeros((h, w, 3), dtype=np.float32)
+    amap = np.zeros((h, w, 3), dtype=np.float32)
+    dev = (C.c_int * 1)(0)
+    rc = rrt.host_lib().rrth_render_folder_first_hits(os.fsencode(os.path.join(rrt.SCENES, "cornell")), dev, 1, 7, spp,
+                                                      None, None, nmap.ctypes.data, amap.ctypes.data)
+    assert rc == 0, rrt.host_lib().rrth_last_error().decode()
+    cam = rrt.Camera.from_settings(rs, w, h)
+    s = rrt.make_settings(w, h, rs.depth_limit, rs.clamp, seed=7)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    try:
+        gpu_ctx.set_option(rrt.OPT_AOVS, 1)
+        gpu_ctx.render(s, 0, spp)
+        n, a = gpu_ctx.aov_download()
+    finally:
+        gpu_ctx.set_option(rrt.OPT_AOVS, 0)
+    np.testing.assert_allclose(nmap, n[..., :3] / spp, atol=1e-6)
+    np.testing.assert_allclose(amap, a[..., :3] / spp, atol=1e-6)
+    lengths = np.linalg.norm(nmap, axis=2)
+    assert (lengths <= 1.0 + 1e-5).all() and (lengths > 0.99).mean() > 0.8  # mostly one face per pixel
+    assert amap.max() <= 1.0 and amap.mean() > 0.1
+
+
 def test_empty_and_degenerate_inputs(rrt, cornell, gpu_ctx):
     scene, rs = cornell
     # a scene with no triangles at all: only a quad light
