@@ -463,8 +463,9 @@ struct ExtendJob {
     Hit h = tri_hit;
     if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
     hit_surface = h.prim >= 0;
-    // shade needs the whole ray, start (for a ray that escaped) its direction and state
-    p.a.trace[slot].ray_d = f4(r.d, __uint_as_float(state));
+    // shade needs the whole ray, start (for a ray that escaped and still has something to collect) its
+    // direction and state
+    if (hit_surface || !p.single || (state & 1u)) p.a.trace[slot].ray_d = f4(r.d, __uint_as_float(state));
     if (hit_surface) {
       p.a.trace[slot].ray_o = f4(r.o, 0.0f);
       p.a.trace[slot].hit = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
