@@ -467,7 +467,7 @@ struct ExtendJob {
     // direction and state
     if (hit_surface || !p.single || (state & 1u)) p.a.trace[slot].ray_d = f4(r.d, __uint_as_float(state));
     if (hit_surface) {
-      p.a.trace[slot].ray_o = f4(r.o, 0.0f);
+      if (h.prim >= sc->n_tris) p.a.trace[slot].ray_o = f4(r.o, 0.0f);  // only the analytic shapes' shading reads it
       p.a.trace[slot].hit = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
     }
     return false;
@@ -556,7 +556,7 @@ struct PrimaryJob {
     Hit h = tri_hit;
     if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
     if (h.prim >= 0) {
-      p.a.trace[slot].ray_o = f4(r.o, 0.0f);
+      if (h.prim >= sc->n_tris) p.a.trace[slot].ray_o = f4(r.o, 0.0f);  // only the analytic shapes' shading reads it
       p.a.trace[slot].ray_d = f4(r.d, __uint_as_float(0u));
       p.a.trace[slot].hit = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
       kind = 1;
@@ -632,8 +632,8 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
   if (i < n) {
     active = true;
     slot = entries[i];
-    const float4 o4 = p.a.trace[slot].ray_o, d4 = p.a.trace[slot].ray_d, h4 = p.a.trace[slot].hit;
-    const V3 org = mk(o4), dir = mk(d4);
+    const float4 d4 = p.a.trace[slot].ray_d, h4 = p.a.trace[slot].hit;
+    const V3 dir = mk(d4);
     uint32_t x, y, k;
     slot_pixel(p, slot, &x, &y, &k);
     // with one sample per slot the sample index follows from the slot number
@@ -644,7 +644,7 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
     const int prim = __float_as_int(h4.x);
     // AreaLight::emitting is zero (lights/area.rs:23-25): hitting an emitter adds nothing
     const Surface s = prim < sc->n_tris ? surface_triangle(p.tris, p.tri_shade, prim, h4.z, h4.w, dir)
-                                        : surface_other(sc, prim, h4.y, org, dir);
+                                        : surface_other(sc, prim, h4.y, mk(p.a.trace[slot].ray_o), dir);
     const DeviceMaterial m = p.materials[s.material];
     const uint32_t pixel = y * p.width + x;
     if (p.aov && bounce == 0) {
