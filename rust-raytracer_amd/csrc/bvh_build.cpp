@@ -65,6 +65,7 @@ constexpr int kBins = RRT_SAH_BINS;
 constexpr uint32_t kMaxLeaf = RRT_MAX_LEAF;  // at most 4: a leaf reference keeps count - 1 in two bits
 constexpr uint32_t kSahDepthLimit = 40;     // below this depth splits fall back to the object median
 constexpr uint32_t kSpawnThreshold = 1u << 16;
+constexpr uint32_t kParallelPassThreshold = 1u << 21;  // triangles in a node from which its passes are split over threads
 
 struct Builder {
   const float* pos;
@@ -92,6 +93,29 @@ struct Builder {
     }
   }
 
+  // Up to `want` of the free threads (the caller gives them back).
+  int take_threads(int want) {
+    int got = 0;
+    while (got < want) {
+      if (free_threads.fetch_sub(1, std::memory_order_relaxed) > 0) ++got;
+      else { free_threads.fetch_add(1, std::memory_order_relaxed); break; }
+    }
+    return got;
+  }
+  // fn(worker, begin, end) over [lo, hi) cut into helpers + 1 ranges, the last one on this thread.
+  template <class Fn>
+  static void for_ranges(uint32_t lo, uint32_t hi, int helpers, Fn fn) {
+    const uint64_t per = ((uint64_t)(hi - lo) + (uint64_t)helpers) / ((uint64_t)helpers + 1);
+    std::vector<std::thread> pool;
+    for (int w = 0; w < helpers; ++w) {
+      const uint32_t a = (uint32_t)std::min<uint64_t>(hi, lo + per * (uint64_t)w), b = (uint32_t)std::min<uint64_t>(hi, (uint64_t)a + per);
+      pool.emplace_back([=]() { fn(w, a, b); });
+    }
+    const uint32_t a = (uint32_t)std::min<uint64_t>(hi, lo + per * (uint64_t)helpers);
+    fn(helpers, a, hi);
+    for (std::thread& t : pool) t.join();
+  }
+
   // Builds the subtree over idx[lo, hi).  Reports how the parent must refer
   // to it: an inner node index (count 0) or a leaf (~lo, count).
   void build(uint32_t lo, uint32_t hi, uint32_t depth, int32_t* child, int32_t* count, Box* box) {
@@ -99,11 +123,33 @@ struct Builder {
     Box bounds, cbounds;
     bounds.reset();
     cbounds.reset();
-    for (uint32_t i = lo; i < hi; ++i) {
-      const size_t t = (size_t)idx[i] * 3;
-      bounds.grow(&tmin[t], &tmax[t]);
-      cbounds.grow_point(&cent[t]);
+    // The passes over a large node's triangles are cut into ranges for whatever threads are free: near
+    // the root there are few subtrees to hand out yet, and one thread walking 50 M triangles per level
+    // was a third of the build.
+    const int helpers = cnt >= kParallelPassThreshold ? take_threads(7) : 0;
+    {
+      struct Partial { Box bounds, cbounds; };
+      std::vector<Partial> part((size_t)helpers + 1);
+      for_ranges(lo, hi, helpers, [&](int w, uint32_t a, uint32_t b) {
+        Partial& pt = part[(size_t)w];
+        pt.bounds.reset();
+        pt.cbounds.reset();
+        for (uint32_t i = a; i < b; ++i) {
+          const size_t t = (size_t)idx[i] * 3;
+          pt.bounds.grow(&tmin[t], &tmax[t]);
+          pt.cbounds.grow_point(&cent[t]);
+        }
+      });
+      for (const Partial& pt : part) {
+        bounds.grow(pt.bounds);
+        cbounds.grow(pt.cbounds);
+      }
     }
+    struct GiveBack {  // the helpers go back before the subtrees are handed out (or at any earlier return)
+      Builder* b; int n;
+      void now() { if (n) b->free_threads.fetch_add(n, std::memory_order_relaxed); n = 0; }
+      ~GiveBack() { now(); }
+    } give_back{this, helpers};
     *box = bounds;
     uint32_t d = max_depth.load(std::memory_order_relaxed);
     while (depth > d && !max_depth.compare_exchange_weak(d, depth, std::memory_order_relaxed)) {}
@@ -129,14 +175,30 @@ struct Builder {
         scale[axis] = extent > 0.0f ? (float)kBins / extent : 0.0f;  // 0: everything in bin 0, no split on this axis
         for (int b = 0; b < kBins; ++b) { bin_box[axis][b].reset(); bin_cnt[axis][b] = 0; }
       }
-      for (uint32_t i = lo; i < hi; ++i) {
-        const size_t t = (size_t)idx[i] * 3;
-        for (int axis = 0; axis < 3; ++axis) {
-          int b = (int)((cent[t + axis] - c0[axis]) * scale[axis]);
-          b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-          bin_cnt[axis][b]++;
-          bin_box[axis][b].grow(&tmin[t], &tmax[t]);
-        }
+      {
+        struct Bins { Box box[3][kBins]; uint32_t cnt[3][kBins]; };
+        std::vector<Bins> part((size_t)helpers + 1);
+        for_ranges(lo, hi, helpers, [&](int w, uint32_t a, uint32_t e) {
+          Bins& bn = part[(size_t)w];
+          for (int axis = 0; axis < 3; ++axis)
+            for (int b = 0; b < kBins; ++b) { bn.box[axis][b].reset(); bn.cnt[axis][b] = 0; }
+          for (uint32_t i = a; i < e; ++i) {
+            const size_t t = (size_t)idx[i] * 3;
+            for (int axis = 0; axis < 3; ++axis) {
+              int b = (int)((cent[t + axis] - c0[axis]) * scale[axis]);
+              b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+              bn.cnt[axis][b]++;
+              bn.box[axis][b].grow(&tmin[t], &tmax[t]);
+            }
+          }
+        });
+        for (const Bins& bn : part)
+          for (int axis = 0; axis < 3; ++axis)
+            for (int b = 0; b < kBins; ++b) {
+              bin_cnt[axis][b] += bn.cnt[axis][b];
+              if (bn.cnt[axis][b]) bin_box[axis][b].grow(bn.box[axis][b]);
+            }
+        give_back.now();
       }
       for (int axis = 0; axis < 3; ++axis) {
         if (!(scale[axis] > 0.0f)) continue;
