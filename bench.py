@@ -70,29 +70,34 @@ def load_buddha(width, height):
     return scene, rs, camera, mesh
 
 
-def cpu_baseline(scene, rs, threads, budget_paths, budget_seconds=0.0):
-    """Times the CPU oracle (port of the reference algorithm) on a bounded sample of the same workload:
-    the same scene, camera, depth and clamp at 1/12 of the resolution in each direction."""
+def cpu_baseline(scene, rs, width, height, threads, budget_paths, budget_seconds=0.0):
+    """Times the CPU oracle (port of the reference algorithm) on a bounded sample of the same workload: the same
+    scene, camera, frame size, depth and clamp, handed out in the reference's 128 x 128 buckets (src/film.rs:134-148;
+    135 of them at 1920 x 1080, so every worker thread has buckets to take), at fewer samples per pixel."""
     from oracle import binding as ob
-    w, h = 160, 90
+    w, h = width, height
     cam = rr.Camera.from_settings(rs, w, h)
     orc = ob.Oracle(scene.desc())
     orc.set_camera(cam)
     s = rr.make_settings(w, h, rs.depth_limit, rs.clamp, seed=0)
+    bucket = (128, 128)
     if budget_seconds > 0:
         # pilot pass to size the sample for about budget_seconds of CPU work
-        _, pilot = orc.render(s, 0, 2, threads=threads)
-        spp = int(min(4096, max(2, budget_seconds * pilot.paths / max(pilot.seconds, 1e-3) / (w * h))))
+        _, pilot = orc.render(s, 0, 1, threads=threads, bucket=bucket)
+        spp = int(min(4096, max(1, budget_seconds * pilot.paths / max(pilot.seconds, 1e-3) / (w * h))))
     else:
         spp = max(1, budget_paths // (w * h))
-    _, st = orc.render(s, 0, spp, threads=threads)
+    _, st = orc.render(s, 1, 1 + spp, threads=threads, bucket=bucket)
     rays = st.rays_extend + st.rays_shadow
     return {
         "value": st.paths / st.seconds,
         "unit": "samples/s",
-        "cores": int(st.threads),
+        "cores": int(st.threads_busy),
+        "threads_started": int(st.threads),
+        "buckets": int(st.buckets),
         "kind": "port",
-        "sample": "same scene/camera/depth at %dx%d, %d spp (%d camera paths), %.1f s" % (w, h, spp, st.paths, st.seconds),
+        "sample": "same scene/camera/depth at %dx%d in %d buckets of %dx%d, %d spp (%d camera paths), %.1f s" % (
+            w, h, st.buckets, bucket[0], bucket[1], spp, st.paths, st.seconds),
         "mrays_per_s": rays / st.seconds * 1e-6,
     }
 
@@ -105,7 +110,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline: seconds of oracle work (0 = use --cpu-paths)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: seconds of oracle work (0 = use --cpu-paths)")
     ap.add_argument("--cpu-paths", type=int, default=0, help="CPU baseline: camera paths when --cpu-seconds is 0 (both 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--batch-samples", type=int, default=0)
@@ -300,7 +305,8 @@ def main():
             "traversal_kernels": kernels,
         }
         if world == 1 and rs is not None and (args.cpu_paths > 0 or args.cpu_seconds > 0):
-            out["cpu_baseline"] = cpu_baseline(scene, rs, args.cpu_threads, args.cpu_paths, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(scene, rs, W, H, args.cpu_threads, args.cpu_paths, args.cpu_seconds)
+            out["cpu_baseline"]["all_threads_busy"] = out["cpu_baseline"]["cores"] == min(args.cpu_threads, out["cpu_baseline"]["buckets"])
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None

@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 class OracleStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays_extend", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("path_bounces", C.c_uint64), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
-                ("seconds", C.c_double), ("threads", C.c_uint32)]
+                ("seconds", C.c_double), ("threads", C.c_uint32), ("threads_busy", C.c_uint32),
+                ("buckets", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 _lib = None

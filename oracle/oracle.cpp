@@ -1050,7 +1050,7 @@ struct LightIrradianceSample {
   double pdf = 0;
 };
 
-struct Counters {
+struct alignas(64) Counters {  // (a cache line each: workers update them per ray)
   uint64_t rays_extend = 0, rays_shadow = 0, path_bounces = 0, nodes_visited = 0, prims_tested = 0, paths = 0;
 };
 
@@ -1565,6 +1565,7 @@ int orc_render(orc_ctx* ctx, const rrt_settings* st, uint32_t sample_begin, uint
   std::mutex film_mutex;  // Arc<RwLock<Film>>
   size_t current_bucket = 0;
   std::vector<Counters> counters(threads);
+  std::vector<uint32_t> buckets_taken(threads, 0u);
   const auto t0 = std::chrono::steady_clock::now();
   auto worker = [&](uint32_t tid) {
     struct SampleResult { double radiance[3]; double p_film[2]; double normal[3]; double albedo[3]; };  // 88 B
@@ -1576,6 +1577,7 @@ int orc_render(orc_ctx* ctx, const rrt_settings* st, uint32_t sample_begin, uint
         std::lock_guard<std::mutex> lock(film_mutex);  // film.write().get_bucket()
         if (current_bucket >= buckets.size()) break;
         b = buckets[current_bucket++];
+        buckets_taken[tid]++;
       }
       // render_work (src/renderer.rs:184-211): every sample of the bucket is kept, then splatted
       std::vector<SampleResult> samples;
@@ -1651,6 +1653,8 @@ int orc_render(orc_ctx* ctx, const rrt_settings* st, uint32_t sample_begin, uint
     }
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->threads = threads;
+    for (uint32_t n : buckets_taken) stats->threads_busy += n > 0 ? 1u : 0u;
+    stats->buckets = (uint32_t)buckets.size();
   }
   return RRT_OK;
 }

@@ -44,6 +44,9 @@ typedef struct orc_stats {
   uint64_t prims_tested;     /* exact shape tests */
   double seconds;            /* wall clock around the bucket loop (src/renderer.rs:121-166) */
   uint32_t threads;
+  uint32_t threads_busy;     /* workers that took at least one bucket */
+  uint32_t buckets;          /* buckets handed out (src/film.rs:134-148) */
+  uint32_t _pad;
 } orc_stats;
 
 orc_ctx* orc_create(const rrt_scene_desc* scene);

@@ -155,3 +155,25 @@ def test_oracle_first_hits_are_consistent(rrt, oracle_binding, cornell):
     table = {tuple(np.round(list(d.materials[i].kd), 6)) for i in range(d.n_materials)}
     seen = {tuple(np.round(a, 6)) for a in albedo[hit][:, :3]}
     assert seen <= table and len(seen) >= 3
+
+
+def test_bucket_queue_keeps_every_worker_busy(rrt, oracle_binding, cornell):
+    """render()'s workers pull 128 x 128 buckets from the film's queue (src/renderer.rs:104-160,
+    src/film.rs:134-148): with many more buckets than workers every worker takes some, and the rate
+    grows with the number of workers -- what the bench's CPU baseline relies on.  With two buckets for
+    four workers (a frame smaller than 2 x 1 buckets) only two of them ever work."""
+    scene, rs = cornell
+    orc = oracle_binding.Oracle(scene.desc())
+    w, h = 512, 384  # 4 x 3 buckets
+    orc.set_camera(rrt.Camera.from_settings(rs, w, h))
+    s = rrt.make_settings(w, h, 3, rs.clamp, seed=1)
+    _, one = orc.render(s, 0, 1, threads=1)
+    _, four = orc.render(s, 0, 1, threads=4)
+    assert one.buckets == four.buckets == 12
+    assert one.threads_busy == 1 and four.threads_busy == 4
+    assert four.paths == one.paths == w * h
+    if (os.cpu_count() or 1) >= 4:
+        assert four.paths / four.seconds > 2.0 * one.paths / one.seconds
+    orc.set_camera(rrt.Camera.from_settings(rs, 160, 90))
+    _, small = orc.render(rrt.make_settings(160, 90, 3, rs.clamp, seed=1), 0, 1, threads=4)
+    assert small.buckets == 2 and small.threads_busy <= 2
