@@ -224,6 +224,18 @@ int rrt_film_reduce(rrt_ctx** ctxs, int n, int root);  /* (and the first-hit buf
  * and its distance. */
 int rrt_intersect(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_t* prim_id, float* t);
 
+/* rrt_intersect without any allocation.  Has no counterpart in the reference: it is for callers that
+ * cannot allocate device memory where they call -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  Same arguments and results as rrt_intersect, but the staging of
+ * the rays, of the results and the kernel's job cursor live in a static device array of the library
+ * (2 MiB + 256 B per GPU, held until the process ends) instead of buffers allocated per call, so n is
+ * limited: more than RRT_NOALLOC_MAX_RAYS rays are rejected with RRT_E_UNSUPPORTED.  The call makes
+ * no hipMalloc / hipFree; with host arrays in pinned memory the copies allocate nothing in the
+ * runtime either.  All contexts of one GPU share that GPU's array: calls that overlap in time on one
+ * GPU (two contexts, two host threads) race -- serialise them. */
+#define RRT_NOALLOC_MAX_RAYS 65536u
+int rrt_intersect_noalloc(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_t* prim_id, float* t);
+
 /* check_intersect_scene_simple (src/renderer.rs:251-275) for n rays given as
  * host [n][7] = origin, direction, max_dist: 1 if anything is hit closer than
  * max_dist. */

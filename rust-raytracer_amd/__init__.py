@@ -93,13 +93,15 @@ LIGHT_POINT, LIGHT_AREA, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2, 3
 RECT_AABB_STRICT, RECT_AABB_INCLUSIVE, RECT_AABB_OFF = 0, 1, 2
 OPT_TIMING, OPT_BATCH_SAMPLES, OPT_MAX_SLOTS, OPT_COUNT_TRAVERSAL, OPT_SIDE_STREAM, OPT_AOVS = 1, 2, 3, 4, 5, 6
 FILTER_NONE, FILTER_GAUSSIAN, FILTER_MITCHELL = 0, 1, 2
+NOALLOC_MAX_RAYS = 65536  # RRT_NOALLOC_MAX_RAYS
 
 # every symbol include/rrt.h and include/rrt_host.h declare
 RRT_SYMBOLS = ["rrt_device_count", "rrt_create", "rrt_destroy", "rrt_set_stream", "rrt_upload_scene",
                "rrt_set_camera", "rrt_film_alloc", "rrt_film_bind", "rrt_film_clear", "rrt_film_download",
                "rrt_film_device_ptr", "rrt_render", "rrt_synchronize", "rrt_film_reduce", "rrt_intersect",
                "rrt_occluded", "rrt_set_option", "rrt_get_stats", "rrt_reset_stats", "rrt_last_error",
-               "rrt_set_filter", "rrt_film_tonemap", "rrt_bvh_selfcheck", "rrt_aov_download", "rrt_aov_device_ptr"]
+               "rrt_set_filter", "rrt_film_tonemap", "rrt_bvh_selfcheck", "rrt_aov_download", "rrt_aov_device_ptr",
+               "rrt_intersect_noalloc"]
 RRTH_SYMBOLS = ["rrth_last_error", "rrth_scene_load", "rrth_scene_load_with_mesh", "rrth_scene_free",
                 "rrth_scene_desc", "rrth_scene_set_rect_aabb_mode", "rrth_scene_set_material",
                 "rrth_load_render_settings", "rrth_camera_matrices", "rrth_camera_generate_ray", "rrth_tonemap",
@@ -140,6 +142,7 @@ def hip_lib():
         lib.rrt_synchronize.argtypes = [C.c_void_p]
         lib.rrt_film_reduce.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
         lib.rrt_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.rrt_intersect_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.rrt_occluded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.rrt_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
         lib.rrt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -484,6 +487,17 @@ class Context:
         prim = np.empty(n, dtype=np.int32)
         t = np.empty(n, dtype=np.float32)
         self._check(self._lib.rrt_intersect(self._h, rays.ctypes.data, n, prim.ctypes.data, t.ctypes.data), "rrt_intersect")
+        return prim, t
+
+    def intersect_noalloc(self, org_dir):
+        """rrt_intersect_noalloc: as intersect(), staged through the library's static device array (at most
+        NOALLOC_MAX_RAYS rays)."""
+        rays = np.ascontiguousarray(org_dir, dtype=np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        prim = np.empty(n, dtype=np.int32)
+        t = np.empty(n, dtype=np.float32)
+        self._check(self._lib.rrt_intersect_noalloc(self._h, rays.ctypes.data, n, prim.ctypes.data, t.ctypes.data),
+                    "rrt_intersect_noalloc")
         return prim, t
 
     def occluded(self, org_dir_tmax):

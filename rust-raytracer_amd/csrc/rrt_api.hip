@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -42,6 +43,40 @@ constexpr uint32_t kQueueGridBlocks = 8192;  // 32 blocks per CU for the kernels
 constexpr uint32_t kTraceGridBlocks = RRT_TRACE_GRID;  // 8 blocks = 32 waves per CU: at least what a CU can hold of the traversal kernels
 
 inline uint32_t grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
+// ---- rrt_intersect_noalloc: device memory that exists without any allocation call.
+// One copy per GPU the library runs on, held until the process ends: the job cursor of the traversal
+// kernel, then staging for RRT_NOALLOC_MAX_RAYS rays (6 floats each), their object ids and distances.
+constexpr size_t kScratchCursorBytes = 256;
+constexpr size_t kScratchRaysAt = kScratchCursorBytes;
+constexpr size_t kScratchPrimAt = kScratchRaysAt + sizeof(float) * 6 * (size_t)RRT_NOALLOC_MAX_RAYS;
+constexpr size_t kScratchTAt = kScratchPrimAt + sizeof(int32_t) * (size_t)RRT_NOALLOC_MAX_RAYS;
+constexpr size_t kScratchBytes = kScratchTAt + sizeof(float) * (size_t)RRT_NOALLOC_MAX_RAYS;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+// In host code `scratch` is only a handle for hipGetSymbolAddress; the address of each GPU's copy is
+// looked up once per device (with that device current) and kept here.
+constexpr int kMaxScratchDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxScratchDevices] = {};
+
+// Address of the current device's copy of `scratch` (the caller has made `device` current), or null.
+unsigned char* scratch_for_device(int device, std::string* error) {
+  if (device < 0 || device >= kMaxScratchDevices) {
+    *error = "device index beyond the scratch table";
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+      *error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+      return nullptr;
+    }
+    g_scratch_ptr[device] = (unsigned char*)ptr;
+  }
+  return g_scratch_ptr[device];
+}
 
 struct EventPair {
   hipEvent_t begin, end;
@@ -92,6 +127,7 @@ struct rrt_ctx {
 
   DeviceStats* d_stats = nullptr;
   uint32_t* d_work = nullptr;     // job cursor of the rrt_intersect / rrt_occluded launches
+  unsigned char* scratch = nullptr;  // this device's copy of the static scratch array (rrt_intersect_noalloc)
   uint32_t* h_pending = nullptr;  // pinned: the two queue-length rows read back between iterations
 
   // options
@@ -492,6 +528,14 @@ rrt_ctx* rrt_create(int device) {
       hipMalloc((void**)&ctx->d_work, sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess) {
     g_create_error = "cannot initialise device " + std::to_string(device);
+    delete ctx;
+    return nullptr;
+  }
+  // (device `device` is current here)
+  ctx->scratch = scratch_for_device(device, &g_create_error);
+  if (!ctx->scratch) {
+    (void)hipFree(ctx->d_stats);
+    (void)hipFree(ctx->d_work);
     delete ctx;
     return nullptr;
   }
@@ -1041,6 +1085,35 @@ int rrt_intersect(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_t* prim_
   (void)hipFree(d_t);
   if (rc != RRT_OK) return rc;
   if (e != hipSuccess) return fail(ctx, RRT_E_DEVICE, std::string("rrt_intersect: ") + hipGetErrorString(e));
+  return RRT_OK;
+}
+
+int rrt_intersect_noalloc(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_t* prim_id, float* t) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!ctx->have_scene) return fail(ctx, RRT_E_STATE, "no scene uploaded");
+  if (n == 0) return RRT_OK;
+  if (!org_dir || !prim_id || !t) return fail(ctx, RRT_E_INVALID, "null array");
+  if (n > RRT_NOALLOC_MAX_RAYS)
+    return fail(ctx, RRT_E_UNSUPPORTED, "rrt_intersect_noalloc: " + std::to_string(n) + " rays exceed RRT_NOALLOC_MAX_RAYS = " +
+                                            std::to_string(RRT_NOALLOC_MAX_RAYS) + "; split the batch or call rrt_intersect");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  // everything below addresses the device's copy of the array through the pointer looked up in rrt_create
+  unsigned char* const base = ctx->scratch;
+  uint32_t* const d_cursor = reinterpret_cast<uint32_t*>(base);
+  float* const d_rays = reinterpret_cast<float*>(base + kScratchRaysAt);
+  int32_t* const d_prim = reinterpret_cast<int32_t*>(base + kScratchPrimAt);
+  float* const d_t = reinterpret_cast<float*>(base + kScratchTAt);
+  // the array keeps the previous call's contents: the cursor must start at zero; the staging areas
+  // are overwritten (rays) or fully written by the kernel (ids, distances) for the n entries read back
+  HIP_TRY(ctx, hipMemsetAsync(d_cursor, 0, kScratchCursorBytes, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_rays, org_dir, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_intersect, dim3(std::min(grid_for(n), kTraceGridBlocks)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes,
+                     ctx->d_tris, ctx->d_scene, d_rays, n, d_prim, d_t, d_cursor);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(prim_id, d_prim, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(t, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return RRT_OK;
 }
 

@@ -1,0 +1,53 @@
+"""rrt_intersect_noalloc against rrt_intersect through the C ABI: the same rays, staged through the
+library's static device array instead of per-call allocations, must give the same object ids and the
+same distances bit for bit (same kernel, same inputs) -- on two calls in a row, the second with a
+smaller input, so that what the first call left in the array must not leak into the second."""
+import numpy as np
+import pytest
+
+import scenes_util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_noalloc_matches_intersect_twice(rrt, oracle_binding, cornell, gpu_ctx):
+    scene, rs = cornell
+    gpu_ctx.upload_scene(scene)
+    orc = oracle_binding.Oracle(scene.desc())
+    rays = scenes_util.ray_set(rrt, orc, rs, 5000, 29).astype(np.float32)
+    assert len(rays) > 6000
+    for n in (len(rays), 777):  # the second, smaller call runs over the first one's leftovers
+        sub = rays[:n] if n == len(rays) else rays[-n:]
+        ref_prim, ref_t = gpu_ctx.intersect(sub)
+        prim, t = gpu_ctx.intersect_noalloc(sub)
+        np.testing.assert_array_equal(prim, ref_prim)
+        np.testing.assert_array_equal(t, ref_t)
+        assert (prim >= 0).sum() > n // 2
+    # and against the oracle on the well separated rays, to the first-hit tolerance
+    o_prim, o_t, margin = orc.intersect(rays.astype(np.float64), with_margin=True)
+    prim, t = gpu_ctx.intersect_noalloc(rays)
+    clear = margin >= 1e-4
+    np.testing.assert_array_equal(prim[clear], o_prim[clear])
+    hit = clear & (o_prim >= 0)
+    scale = np.maximum(o_t[hit], np.abs(rays[hit, :3]).max(axis=1))
+    assert (np.abs(t[hit] - o_t[hit]) <= 1e-5 * scale).all()
+
+
+def test_noalloc_limits(rrt, cornell, gpu_ctx):
+    scene, _ = cornell
+    gpu_ctx.upload_scene(scene)
+    prim, _ = gpu_ctx.intersect_noalloc(np.zeros((0, 6), dtype=np.float32))
+    assert len(prim) == 0
+    rays = np.zeros((rrt.NOALLOC_MAX_RAYS + 1, 6), dtype=np.float32)
+    rays[:, 4] = 1.0
+    with pytest.raises(rrt.RrtError, match="RRT_NOALLOC_MAX_RAYS"):
+        gpu_ctx.intersect_noalloc(rays)
+    # exactly the maximum is accepted and agrees with the allocating entry point
+    rng = np.random.default_rng(1)
+    full = np.concatenate([rng.uniform(-0.9, 0.9, (rrt.NOALLOC_MAX_RAYS, 3)), rng.normal(size=(rrt.NOALLOC_MAX_RAYS, 3))], axis=1)
+    full[:, 3:] /= np.linalg.norm(full[:, 3:], axis=1, keepdims=True)
+    full = full.astype(np.float32)
+    a = gpu_ctx.intersect(full)
+    b = gpu_ctx.intersect_noalloc(full)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
