@@ -21,8 +21,11 @@
 #include <vector>
 
 #include "rrt_device.h"
+#include "rrt_threads.h"
 
 namespace rrt {
+
+std::atomic<int> g_thread_creations_allowed{-1};
 
 namespace {
 
@@ -76,6 +79,7 @@ struct Builder {
   std::atomic<uint32_t> node_count{0};
   std::atomic<int> free_threads{0};
   std::atomic<uint32_t> max_depth{0};
+  std::atomic<bool> failed{false};  // a worker thread ran out of memory: the tree is incomplete
 
   void prepare() {
     tmin.resize((size_t)n * 3);
@@ -102,18 +106,22 @@ struct Builder {
     }
     return got;
   }
-  // fn(worker, begin, end) over [lo, hi) cut into helpers + 1 ranges, the last one on this thread.
+  // fn(worker, begin, end) over [lo, hi) cut into helpers + 1 ranges, the last one on this thread (and
+  // any range whose thread could not be started).  fn must not throw: it only reads and writes
+  // memory its caller has set up.
   template <class Fn>
   static void for_ranges(uint32_t lo, uint32_t hi, int helpers, Fn fn) {
     const uint64_t per = ((uint64_t)(hi - lo) + (uint64_t)helpers) / ((uint64_t)helpers + 1);
-    std::vector<std::thread> pool;
+    std::thread pool[8];
+    if (helpers > 8) helpers = 8;
+    JoinGuard join{pool, helpers};
     for (int w = 0; w < helpers; ++w) {
       const uint32_t a = (uint32_t)std::min<uint64_t>(hi, lo + per * (uint64_t)w), b = (uint32_t)std::min<uint64_t>(hi, (uint64_t)a + per);
-      pool.emplace_back([=]() { fn(w, a, b); });
+      auto run = [=]() { fn(w, a, b); };
+      if (!try_spawn(&pool[w], run)) run();
     }
     const uint32_t a = (uint32_t)std::min<uint64_t>(hi, lo + per * (uint64_t)helpers);
     fn(helpers, a, hi);
-    for (std::thread& t : pool) t.join();
   }
 
   // Builds the subtree over idx[lo, hi).  Reports how the parent must refer
@@ -255,21 +263,33 @@ struct Builder {
     Node2 node;
     std::memset(&node, 0, sizeof(node));
     Box lb, rb;
-    int32_t lc, lcount, rc, rcount;
+    lb.reset();
+    rb.reset();
+    int32_t lc = ~0, lcount = 1, rc = ~0, rcount = 1;  // (what a subtree abandoned on an allocation failure leaves behind)
     bool spawned = false;
     std::thread worker;
-    if (cnt >= kSpawnThreshold && free_threads.fetch_sub(1, std::memory_order_relaxed) > 0) {
-      spawned = true;
-      worker = std::thread([&]() { build(lo, mid, depth + 1, &lc, &lcount, &lb); });
-    } else if (cnt >= kSpawnThreshold) {
-      free_threads.fetch_add(1, std::memory_order_relaxed);
+    if (cnt >= kSpawnThreshold) {
+      if (free_threads.fetch_sub(1, std::memory_order_relaxed) > 0) {
+        JoinGuard join{&worker, 1};  // joined also when the right subtree below throws
+        auto left = [&]() { guarded(&failed, [&]() { build(lo, mid, depth + 1, &lc, &lcount, &lb); }); };
+        spawned = try_spawn(&worker, left);
+        if (!spawned) build(lo, mid, depth + 1, &lc, &lcount, &lb);
+        struct Return {  // the thread goes back to the pool once the left subtree is done or abandoned
+          Builder* b;
+          ~Return() { b->free_threads.fetch_add(1, std::memory_order_relaxed); }
+        } give{this};
+        build(mid, hi, depth + 1, &rc, &rcount, &rb);
+        if (worker.joinable()) worker.join();
+      } else {
+        free_threads.fetch_add(1, std::memory_order_relaxed);
+        build(lo, mid, depth + 1, &lc, &lcount, &lb);
+        build(mid, hi, depth + 1, &rc, &rcount, &rb);
+      }
+    } else {
+      build(lo, mid, depth + 1, &lc, &lcount, &lb);
+      build(mid, hi, depth + 1, &rc, &rcount, &rb);
     }
-    if (!spawned) build(lo, mid, depth + 1, &lc, &lcount, &lb);
-    build(mid, hi, depth + 1, &rc, &rcount, &rb);
-    if (spawned) {
-      worker.join();
-      free_threads.fetch_add(1, std::memory_order_relaxed);
-    }
+    (void)spawned;
     for (int k = 0; k < 3; ++k) {
       node.lmin[k] = lb.mn[k]; node.lmax[k] = lb.mx[k];
       node.rmin[k] = rb.mn[k]; node.rmax[k] = rb.mx[k];
@@ -291,6 +311,7 @@ struct Collapser {
   BvhNode* out = nullptr;
   std::atomic<uint32_t> max_depth{0};
   std::atomic<int> free_threads{0};
+  std::atomic<bool> failed{false};
 
   struct Child {
     Box box;
@@ -333,21 +354,32 @@ struct Collapser {
   void for_inner_children(const Child* c, int n, uint32_t depth, Fn fn) {
     std::thread workers[4];
     int n_workers = 0;
+    struct Finish {  // joins the workers and gives their threads back, on every way out
+      Collapser* self; std::thread* workers; int* n;
+      ~Finish() {
+        for (int w = 0; w < *n; ++w) {
+          if (workers[w].joinable()) workers[w].join();
+          self->free_threads.fetch_add(1, std::memory_order_relaxed);
+        }
+      }
+    } finish{this, workers, &n_workers};
     int last_inner = -1;
     for (int i = 0; i < n; ++i)
       if (c[i].inner) last_inner = i;
     for (int i = 0; i < n; ++i) {
       if (!c[i].inner) continue;
-      if (i != last_inner && depth <= 6 && free_threads.fetch_sub(1, std::memory_order_relaxed) > 0) {
-        workers[n_workers++] = std::thread([=]() { fn(i); });
-      } else {
-        if (i != last_inner && depth <= 6) free_threads.fetch_add(1, std::memory_order_relaxed);
-        fn(i);
+      bool started = false;
+      if (i != last_inner && depth <= 6) {
+        if (free_threads.fetch_sub(1, std::memory_order_relaxed) > 0) {
+          auto run = [=]() { guarded(&failed, [&]() { fn(i); }); };
+          started = try_spawn(&workers[n_workers], run);
+          if (started) ++n_workers;
+          else free_threads.fetch_add(1, std::memory_order_relaxed);
+        } else {
+          free_threads.fetch_add(1, std::memory_order_relaxed);
+        }
       }
-    }
-    for (int w = 0; w < n_workers; ++w) {
-      workers[w].join();
-      free_threads.fetch_add(1, std::memory_order_relaxed);
+      if (!started) fn(i);
     }
   }
 
@@ -421,12 +453,9 @@ struct Collapser {
 
 }  // namespace
 
-bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuildResult* out) {
-  *out = BvhBuildResult();
+namespace {
+bool build_bvh_impl(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuildResult* out, Node2* scratch, uint32_t* order, uint32_t** below_out) {
   const uint32_t cap = n_tris > 1 ? n_tris : 1;
-  Node2* scratch = (Node2*)std::malloc(sizeof(Node2) * (size_t)cap);
-  uint32_t* order = (uint32_t*)std::malloc(sizeof(uint32_t) * (size_t)cap);
-  if (!scratch || !order) { std::free(scratch); std::free(order); return false; }
 
   auto empty_child = [](float* mn, float* mx) {
     for (int k = 0; k < 3; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
@@ -455,6 +484,7 @@ bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuild
     int32_t child, count;
     Box box;
     b.build(0, n_tris, 0, &child, &count, &box);
+    if (b.failed) return false;
     if (std::getenv("RRT_BVH_TIMING"))
       std::fprintf(stderr, "bvh build: %u triangles, %u threads: bounds %.2f s, binary tree %.2f s\n", n_tris, threads,
                    std::chrono::duration<double>(t1 - t0).count(),
@@ -476,35 +506,57 @@ bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuild
   Collapser col;
   col.in = scratch;
   col.below = (uint32_t*)std::calloc(cap, sizeof(uint32_t));
-  if (!col.below) { std::free(scratch); std::free(order); return false; }
+  *below_out = col.below;  // (freed by the caller, whichever way this function is left)
+  if (!col.below) return false;
   if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
   if (threads > 64) threads = 64;
   col.free_threads = (int)threads - 1;
   BvhNode* nodes = nullptr;
   uint32_t n_nodes = 0;
-  bool ok = true;
-  try {
-    n_nodes = col.count(0, 1);
-    ok = posix_memalign((void**)&nodes, alignof(BvhNode), sizeof(BvhNode) * (size_t)n_nodes) == 0;
-    if (ok) {
-      col.out = nodes;
-      col.emit(0, 0, 1);
-    }
-  } catch (const std::exception&) {  // thread creation can fail
-    ok = false;
-  }
-  std::free(col.below);
-  std::free(scratch);
-  if (!ok) { std::free(nodes); std::free(order); return false; }
+  n_nodes = col.count(0, 1);
+  if (col.failed) return false;
+  if (posix_memalign((void**)&nodes, alignof(BvhNode), sizeof(BvhNode) * (size_t)n_nodes) != 0) return false;
+  out->nodes = nodes;  // (the caller frees it if anything below fails)
+  col.out = nodes;
+  col.emit(0, 0, 1);
+  if (col.failed) return false;
   if (std::getenv("RRT_BVH_TIMING"))
     std::fprintf(stderr, "bvh build: collapse to %u 4-wide nodes %.2f s\n", n_nodes,
                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t_collapse).count());
-  out->nodes = nodes;
   out->n_nodes = n_nodes;
-  out->order = order;
   out->max_depth = col.max_depth;
   return true;
 }
+}  // namespace
+
+// Never throws: running out of memory or of threads anywhere below gives false (a thread that cannot
+// be started is not an error: its share of the work runs on the thread that wanted it).
+bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuildResult* out) {
+  *out = BvhBuildResult();
+  const uint32_t cap = n_tris > 1 ? n_tris : 1;
+  Node2* scratch = (Node2*)std::malloc(sizeof(Node2) * (size_t)cap);
+  uint32_t* order = (uint32_t*)std::malloc(sizeof(uint32_t) * (size_t)cap);
+  uint32_t* below = nullptr;
+  bool ok = scratch && order;
+  if (ok) {
+    try {
+      ok = build_bvh_impl(tri_pos, n_tris, threads, out, scratch, order, &below);
+    } catch (...) {  // std::bad_alloc from the builder's vectors
+      ok = false;
+    }
+  }
+  std::free(below);
+  std::free(scratch);
+  if (!ok) {
+    std::free(out->nodes);
+    std::free(order);
+    *out = BvhBuildResult();
+    return false;
+  }
+  out->order = order;
+  return true;
+}
+
 
 namespace {
 
@@ -564,7 +616,7 @@ struct Validator {
 
 uint64_t validate_bvh(const float* tri_pos, uint32_t n_tris, const BvhBuildResult& b) {
   if (n_tris == 0 || b.n_nodes == 0) return 0;
-  Validator v{tri_pos, b, n_tris, std::vector<uint8_t>(n_tris, 0), 0};
+  Validator v{tri_pos, b, n_tris, std::vector<uint8_t>(n_tris, 0), 0};  // (may throw std::bad_alloc: callers catch)
   double mn[3], mx[3];
   v.bounds(0, 1, mn, mx);
   for (uint32_t t = 0; t < n_tris; ++t)

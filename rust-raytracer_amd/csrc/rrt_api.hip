@@ -18,6 +18,7 @@
 #include "../../include/rrt.h"
 #include "rrt_device.h"
 #include "rrt_kernels.h"
+#include "rrt_threads.h"
 
 using namespace rrt;
 
@@ -200,7 +201,8 @@ int dev_alloc(rrt_ctx* ctx, T** out, size_t count) {
   return RRT_OK;
 }
 
-// fn(i) for i in [0, n), in contiguous ranges on up to 32 host threads (small n: on this one).
+// fn(i) for i in [0, n), in contiguous ranges on up to 32 host threads (small n: on this one).  fn must
+// not throw.  A range whose thread cannot be started runs on the calling thread.
 template <class Fn>
 void parallel_for(uint32_t n, Fn fn) {
   const uint32_t workers = n < (1u << 18) ? 1u : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
@@ -208,14 +210,15 @@ void parallel_for(uint32_t n, Fn fn) {
     for (uint32_t i = 0; i < n; ++i) fn(i);
     return;
   }
-  std::vector<std::thread> pool;
+  std::thread pool[32];
+  JoinGuard join{pool, (int)workers};
   const uint64_t per = ((uint64_t)n + workers - 1) / workers;
   for (uint32_t w = 0; w < workers; ++w) {
     const uint64_t lo = per * w, hi = std::min<uint64_t>(n, lo + per);
     if (lo >= hi) break;
-    pool.emplace_back([=]() { for (uint64_t i = lo; i < hi; ++i) fn((uint32_t)i); });
+    auto run = [=]() { for (uint64_t i = lo; i < hi; ++i) fn((uint32_t)i); };
+    if (!try_spawn(&pool[w], run)) run();
   }
-  for (std::thread& t : pool) t.join();
 }
 
 template <typename T>
@@ -416,6 +419,18 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_connect, hipEventDisableTiming));
   }
   bool connect_outstanding = false;  // a connect on the side stream that the main stream has not joined yet
+  // Whichever way the pass is left: the caller's stream waits for a connect still running on the side
+  // stream (the next call's kernels rewrite the records it reads), and a pass that failed leaves no
+  // half-recorded timing events behind.
+  struct PassGuard {
+    rrt_ctx* ctx;
+    bool* outstanding;
+    bool completed = false;
+    ~PassGuard() {
+      if (*outstanding) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_connect, 0);
+      if (!completed) ctx->events_used = 0;
+    }
+  } pass_guard{ctx, &connect_outstanding};
   uint64_t it = 0;
   uint32_t burst = per_slot + 1;
   for (;;) {
@@ -479,7 +494,10 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
     if (it >= max_iterations) return fail(ctx, RRT_E_DEVICE, "path queues did not drain");
     burst = (uint32_t)std::min<uint64_t>(4, max_iterations - it);
   }
-  if (connect_outstanding) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_connect, 0));
+  if (connect_outstanding) {
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_connect, 0));
+    connect_outstanding = false;
+  }
   if ((rc = record_begin(ctx, 4)) != RRT_OK) return rc;
   // with a reconstruction filter the samples went into the film as their paths ended
   if (!p.filter_table) {
@@ -491,6 +509,7 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
   hipLaunchKernelGGL(k_pass_stats, dim3(1), dim3(64), 0, ctx->stream, p);
   if ((rc = record_end(ctx)) != RRT_OK) return rc;
   HIP_TRY(ctx, hipGetLastError());
+  pass_guard.completed = true;
   return collect_timing(ctx);
 }
 
@@ -573,8 +592,8 @@ int rrt_set_stream(rrt_ctx* ctx, void* hip_stream) {
   return RRT_OK;
 }
 
-int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* sd) {
-  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+namespace {
+int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   if (!sd) return fail(ctx, RRT_E_INVALID, "null scene");
   if (sd->n_tris && (!sd->tri_pos || !sd->tri_nrm || !sd->tri_mat)) return fail(ctx, RRT_E_INVALID, "null triangle arrays");
   if ((sd->n_rects && !sd->rects) || (sd->n_planes && !sd->planes) || (sd->n_spheres && !sd->spheres) ||
@@ -602,6 +621,10 @@ int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* sd) {
 
   // ---- BVH over the triangles, then the leaf-ordered records
   BvhBuildResult bvh;
+  struct BvhOwner {  // frees the hierarchy on every way out (free_bvh leaves it empty, so the explicit calls below are harmless)
+    BvhBuildResult* b;
+    ~BvhOwner() { free_bvh(b); }
+  } bvh_owner{&bvh};
   if (!build_bvh(sd->tri_pos, sd->n_tris, 0, &bvh)) return fail(ctx, RRT_E_NOMEM, "BVH build: out of host memory");
   // (malloc'ed, not vectors: 100 bytes per triangle that need no zeroing first)
   TriIsect* tris = (TriIsect*)std::malloc(sizeof(TriIsect) * std::max<size_t>(sd->n_tris, 1));
@@ -747,6 +770,17 @@ int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   ctx->bvh_bytes = sizeof(BvhNode) * (uint64_t)ctx->n_nodes + (sizeof(TriIsect) + sizeof(TriShade)) * (uint64_t)sd->n_tris;
   ctx->have_scene = true;
   return RRT_OK;
+}
+}  // namespace
+
+int rrt_upload_scene(rrt_ctx* ctx, const rrt_scene_desc* sd) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  try {
+    return upload_scene_impl(ctx, sd);
+  } catch (...) {  // std::bad_alloc from a host container: nothing may unwind across the C boundary
+    free_scene(ctx);
+    return fail(ctx, RRT_E_NOMEM, "rrt_upload_scene: out of host memory");
+  }
 }
 
 int rrt_set_camera(rrt_ctx* ctx, const double raster_to_camera[16], const double camera_to_world[16], double aperture,
@@ -921,8 +955,8 @@ int rrt_film_tonemap(rrt_ctx* ctx, uint8_t* host_rgb8) {
   return RRT_OK;
 }
 
-int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint32_t sample_end) {
-  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+namespace {
+int render_impl(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint32_t sample_end) {
   if (!s) return fail(ctx, RRT_E_INVALID, "null settings");
   if (!ctx->have_scene) return fail(ctx, RRT_E_STATE, "no scene uploaded");
   if (!ctx->have_camera) return fail(ctx, RRT_E_STATE, "no camera set");
@@ -1044,6 +1078,16 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
     }
   }
   return RRT_OK;
+}
+}  // namespace
+
+int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint32_t sample_end) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  try {
+    return render_impl(ctx, s, sample_begin, sample_end);
+  } catch (...) {  // std::bad_alloc (the list of state allocations, the timing events, an error string)
+    return RRT_E_NOMEM;
+  }
 }
 
 int rrt_synchronize(rrt_ctx* ctx) {
@@ -1223,8 +1267,15 @@ int64_t rrt_bvh_selfcheck(const float* tri_pos, uint32_t n_tris, uint32_t* n_nod
   if (!build_bvh(tri_pos, n_tris, 0, &bvh)) return RRT_E_NOMEM;
   if (n_nodes) *n_nodes = bvh.n_nodes;
   if (max_depth) *max_depth = bvh.max_depth;
-  const uint64_t bad = validate_bvh(tri_pos, n_tris, bvh);
+  uint64_t bad = 0;
+  bool ok = true;
+  try {
+    bad = validate_bvh(tri_pos, n_tris, bvh);
+  } catch (...) {  // its table of visited triangles
+    ok = false;
+  }
   free_bvh(&bvh);
+  if (!ok) return RRT_E_NOMEM;
   return (int64_t)std::min<uint64_t>(bad, (uint64_t)INT64_MAX);
 }
 
@@ -1297,6 +1348,11 @@ int rrt_film_reduce(rrt_ctx** ctxs, int n, int root) {
   if (rc != RRT_OK) return fail(ctxs[root], rc, "ncclReduce failed");
   return RRT_OK;
 }
+
+// Test hook, not part of include/rrt.h: after `n` more host threads every further thread creation of
+// the library is refused as if the system had none left (n < 0: back to normal).  The library must
+// then do the refused thread's work on the thread that asked, with the same result.
+void rrt_debug_fail_threads_after(int n) { g_thread_creations_allowed.store(n < 0 ? -1 : n); }
 
 const char* rrt_last_error(rrt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 

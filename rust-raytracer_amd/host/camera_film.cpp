@@ -237,11 +237,20 @@ Film::Film(uint32_t width, uint32_t height, uint32_t bucket_w, uint32_t bucket_h
 
 void Film::render_window(uint32_t* x0, uint32_t* y0, uint32_t* x1, uint32_t* y1) const {
   if (has_crop_) {
-    // buckets start at crop_start and are capped at the image size (src/film.rs:270-283)
-    *x0 = crop_[0];
-    *y0 = crop_[1];
-    *x1 = crop_[2] < width_ ? crop_[2] : width_;
-    *y1 = crop_[3] < height_ ? crop_[3] : height_;
+    // Film::init_buckets (src/film.rs:263-283): ceil((crop_end - crop_start) / bucket) WHOLE buckets
+    // are laid from crop_start and capped only at the image size, so with a crop that is not a
+    // multiple of the bucket size the reference also renders the pixels between crop_end and the
+    // next bucket edge.  The window handed to the device is that union of buckets.
+    const uint32_t bw = bucket_w_ ? bucket_w_ : 1, bh = bucket_h_ ? bucket_h_ : 1;
+    const uint32_t cw = crop_[2] > crop_[0] ? crop_[2] - crop_[0] : 0, ch = crop_[3] > crop_[1] ? crop_[3] - crop_[1] : 0;
+    const uint64_t ex = (uint64_t)crop_[0] + (uint64_t)((cw + bw - 1) / bw) * bw;
+    const uint64_t ey = (uint64_t)crop_[1] + (uint64_t)((ch + bh - 1) / bh) * bh;
+    *x0 = crop_[0] < width_ ? crop_[0] : width_;
+    *y0 = crop_[1] < height_ ? crop_[1] : height_;
+    *x1 = (uint32_t)(ex < width_ ? ex : width_);
+    *y1 = (uint32_t)(ey < height_ ? ey : height_);
+    if (*x1 < *x0) *x1 = *x0;
+    if (*y1 < *y0) *y1 = *y0;
   } else {
     *x0 = 0;
     *y0 = 0;

@@ -284,7 +284,13 @@ def test_yaml_typed_accessors(rrt, tmp_path):
     (folder / "render_settings.yaml").write_text(base.replace("#  crop:\n#    start: [300,300]\n#    end: [400,400]",
                                                               "  crop:\n    start: [300,310]\n    end: [400,420]"))
     rs = rrt.load_render_settings(str(folder))
-    assert (rs.crop_x0, rs.crop_y0, rs.crop_x1, rs.crop_y1) == (300, 310, 400, 420)
+    # Film::init_buckets lays whole 128 x 128 buckets from crop.start (src/film.rs:263-283): a 100 x 110 crop
+    # is one bucket, and the rendered window reaches the bucket's edge, beyond crop.end
+    assert (rs.crop_x0, rs.crop_y0, rs.crop_x1, rs.crop_y1) == (300, 310, 428, 438)
+    (folder / "render_settings.yaml").write_text(base.replace("#  crop:\n#    start: [300,300]\n#    end: [400,400]",
+                                                              "  crop:\n    start: [700,0]\n    end: [960,256]"))
+    rs = rrt.load_render_settings(str(folder))
+    assert (rs.crop_x0, rs.crop_y0, rs.crop_x1, rs.crop_y1) == (700, 0, 1000, 256)  # three buckets wide, capped at the image
     (folder / "render_settings.yaml").write_text(base.replace("fov: 38.0", "fov: 38"))
     with pytest.raises(rrt.RrtError):  # .as_f64().unwrap() panics in the reference
         rrt.load_render_settings(str(folder))
@@ -312,3 +318,28 @@ def test_tonemap_matches_the_oracle_pixel(rrt, oracle_binding):
             assert img[y, x].tolist() == list(out)
     # white (1,1,1) goes through the XYZ->sRGB matrix: (1.2048, 0.9483, 0.9089) before gamma
     assert img[0, 1].tolist() == [255, int((0.948291 ** (1 / 2.4) * 1.055 - 0.055) * 255), int((0.908916 ** (1 / 2.4) * 1.055 - 0.055) * 255)]
+
+
+def test_refused_threads_change_nothing(rrt):
+    """The builder spreads its passes and subtrees over host threads.  When the system refuses a thread
+    (here: a test hook that refuses every creation after the first n) the work runs on the thread that
+    asked for it: same hierarchy, no exception across the C boundary, no abort."""
+    import ctypes as C
+    lib = rrt.hip_lib()
+    lib.rrt_debug_fail_threads_after.argtypes = [C.c_int]
+    lib.rrt_debug_fail_threads_after.restype = None
+    rng = np.random.default_rng(2)
+    n = 150000  # above the builder's threshold for handing subtrees to threads
+    centre = rng.uniform(-10, 10, size=(n, 1, 3))
+    tri = (centre + rng.normal(scale=0.05, size=(n, 3, 3))).astype(np.float32)
+    results = []
+    try:
+        for allowed in (-1, 0, 1, 3):
+            lib.rrt_debug_fail_threads_after(allowed)
+            nodes, depth = C.c_uint32(), C.c_uint32()
+            bad = lib.rrt_bvh_selfcheck(tri.ctypes.data, n, C.byref(nodes), C.byref(depth))
+            assert bad == 0, (allowed, bad)
+            results.append((nodes.value, depth.value))
+    finally:
+        lib.rrt_debug_fail_threads_after(-1)
+    assert len(set(results)) == 1, results
