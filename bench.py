@@ -118,6 +118,10 @@ def main():
     ap.add_argument("--no-calibrate", action="store_true")
     ap.add_argument("--workload", choices=["buddha", "stress", "cornell", "cornell-matte"], default="buddha",
                     help="buddha: the headline configuration; stress: cow/lamp/teapot trios on a grid (depth 16)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --spp samples per pixel on EVERY GPU (rank r renders [r spp, (r+1) spp)); strong: --spp in total, "
+                         "rank r renders [r spp / N, (r+1) spp / N) (the 3840x2160, 4096 spp configuration: --scaling strong "
+                         "--width 3840 --height 2160 --spp 4096)")
     ap.add_argument("--trios", type=int, default=3200, help="stress workload: number of trios (15,632 triangles each)")
     args = ap.parse_args()
 
@@ -140,13 +144,14 @@ def main():
     torch.cuda.set_device(device)
 
     W, H, SPP = args.width, args.height, args.spp
+    spp_label = "per GPU" if args.scaling == "weak" else "in total over all GPUs"
     if args.workload == "stress":
         t_gen = time.perf_counter()
         scene, cam_args, depth_limit, clamp = stress.stress_scene(rr, args.trios)
         camera = rr.Camera(image_width=W, image_height=H, **cam_args)
         mesh = "%d generated trios" % args.trios
-        workload = "stress: %d cow/lamp/teapot trios on a grid, %dx%d, %d spp per GPU, depth %d, clamp %g, matte, distant + area light" % (
-            args.trios, W, H, SPP, depth_limit, clamp)
+        workload = "stress: %d cow/lamp/teapot trios on a grid, %dx%d, %d spp %s, depth %d, clamp %g, matte, distant + area light" % (
+            args.trios, W, H, SPP, spp_label, depth_limit, clamp)
         rs = None
         if rank == 0:
             print("stress scene generated in %.1f s" % (time.perf_counter() - t_gen), file=sys.stderr, flush=True)
@@ -164,13 +169,13 @@ def main():
         camera = rr.Camera.from_settings(rs, W, H)
         mesh = "cornell.obj"
         depth_limit, clamp = rs.depth_limit, rs.clamp
-        workload = "scene/cornell %dx%d, %d spp per GPU, depth %d, clamp %g, %s, area light" % (
-            W, H, SPP, depth_limit, clamp, "all materials matte" if args.workload == "cornell-matte" else "materials as shipped")
+        workload = "scene/cornell %dx%d, %d spp %s, depth %d, clamp %g, %s, area light" % (
+            W, H, SPP, spp_label, depth_limit, clamp, "all materials matte" if args.workload == "cornell-matte" else "materials as shipped")
     else:
         scene, rs, camera, mesh = load_buddha(W, H)
         depth_limit, clamp = rs.depth_limit, rs.clamp
-        workload = ("scene/buddha %dx%d, %d spp per GPU, depth %d, clamp %g, aperture %g, microfacet plastic, "
-                    "3 area + distant + environment lights with MIS" % (W, H, SPP, depth_limit, clamp, rs.aperture))
+        workload = ("scene/buddha %dx%d, %d spp %s, depth %d, clamp %g, aperture %g, microfacet plastic, "
+                    "3 area + distant + environment lights with MIS" % (W, H, SPP, spp_label, depth_limit, clamp, rs.aperture))
     ctx = rr.Context(local_rank)
     t_up = time.perf_counter()
     ctx.upload_scene(scene)
@@ -185,7 +190,11 @@ def main():
     if args.batch_samples:
         ctx.set_option(rr.OPT_BATCH_SAMPLES, args.batch_samples)
     settings = rr.make_settings(W, H, depth_limit, clamp, seed=0)
-    s_begin, s_end = rrdist.weak_sample_range(rank, SPP)
+    if args.scaling == "strong":
+        s_begin, s_end = rrdist.sample_range(rank, world, SPP)
+    else:
+        s_begin, s_end = rrdist.weak_sample_range(rank, SPP)
+    total_spp = SPP if args.scaling == "strong" else SPP * world
 
     def step():
         film.zero_()
@@ -204,7 +213,7 @@ def main():
         ctx.set_option(rr.OPT_COUNT_TRAVERSAL, 1)
         ctx.reset_stats()
         film.zero_()
-        ctx.render(settings, s_begin, s_begin + min(8, SPP))
+        ctx.render(settings, s_begin, s_begin + min(8, s_end - s_begin))
         st = ctx.stats()
         rays = (st.rays_primary, st.rays_extend - st.rays_primary, st.rays_shadow)
         per_ray = [(st.nodes_by_kernel[k] / max(rays[k], 1), st.tris_by_kernel[k] / max(rays[k], 1)) for k in range(3)]
@@ -240,14 +249,14 @@ def main():
         film.copy_(keep)
     ctx.set_option(rr.OPT_TIMING, 0)
 
-    paths_all = float(W) * H * SPP * args.steps * world
+    paths_all = float(W) * H * total_spp * args.steps
     value = paths_all / elapsed
     rays_rank = st.rays_extend + st.rays_shadow
     out = None
     if rank == 0:
         # sanity: the film holds `world` x SPP samples per pixel and finite radiance
         fsum = film.sum(dim=(0, 1)).tolist()
-        assert abs(fsum[3] - float(W) * H * SPP * world) < 1e-3 * W * H * SPP * world, fsum
+        assert abs(fsum[3] - float(W) * H * total_spp) < 1e-3 * W * H * total_spp, fsum
         assert all(x == x and x > 0 for x in fsum[:3]), fsum
         roofline = None
         kernels = None
@@ -287,13 +296,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "mesh": mesh, "triangles": int(scene.desc().n_tris),
                        "bvh_nodes": int(st.bvh_nodes), "scene_bytes": int(st.bvh_bytes), "scene_upload_s": upload_s,
-                       "sharding": "sample index ranges per GPU"},
+                       "sharding": "sample index ranges per GPU", "samples_per_pixel_total": total_spp,
+                       "samples_per_pixel_this_rank": s_end - s_begin},
             "mrays_per_s": rays_rank * world / elapsed * 1e-6,
             "rays_per_path": rays_rank / float(st.paths) if st.paths else None,
             "bounces_per_path": st.path_bounces / float(st.paths) if st.paths else None,

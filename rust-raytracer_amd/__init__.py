@@ -403,6 +403,15 @@ def tonemap(sum_rgbw):
 
 
 # --------------------------------------------------------------------------- device context
+def film_reduce(contexts, root=0):
+    """rrt_film_reduce: sums the films (and first-hit buffers) of one context per GPU onto contexts[root]."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    rc = hip_lib().rrt_film_reduce(arr, len(contexts), root)
+    if rc != 0:
+        msg = hip_lib().rrt_last_error(contexts[root]._h if 0 <= root < len(contexts) else None)
+        raise RrtError("rrt_film_reduce failed (%d): %s" % (rc, (msg or b"").decode()))
+
+
 class Context:
     """One GPU's rrt_ctx (include/rrt.h)."""
 

@@ -25,6 +25,8 @@ using namespace rrt;
 namespace {
 
 thread_local std::string g_create_error;
+std::atomic<int> g_live_contexts{0};  // contexts alive in this process
+void destroy_comm_sets();              // frees the RCCL communicators rrt_film_reduce keeps
 
 constexpr uint32_t kSlotLimit = 1u << 30;          // slot numbers share a word with two flag bits
 #ifndef RRT_AUTO_MEMORY_SHARE
@@ -558,6 +560,7 @@ rrt_ctx* rrt_create(int device) {
     delete ctx;
     return nullptr;
   }
+  g_live_contexts.fetch_add(1);
   return ctx;
 }
 
@@ -584,6 +587,7 @@ void rrt_destroy(rrt_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_connect);
   }
   delete ctx;
+  if (g_live_contexts.fetch_sub(1) == 1) destroy_comm_sets();  // the last context takes the cached communicators with it
 }
 
 int rrt_set_stream(rrt_ctx* ctx, void* hip_stream) {
@@ -1291,6 +1295,103 @@ int rrt_reset_stats(rrt_ctx* ctx) {
 }
 
 // RCCL is loaded on first use so that single-GPU users never pay for it.
+extern "C++" {
+namespace {
+typedef void* comm_t;
+struct RcclApi {
+  int (*comm_init_all)(comm_t*, int, const int*) = nullptr;
+  int (*reduce)(const void*, void*, size_t, int, int, int, comm_t, hipStream_t) = nullptr;
+  int (*group_start)(void) = nullptr;
+  int (*group_end)(void) = nullptr;
+  int (*comm_destroy)(comm_t) = nullptr;
+  bool ok = false;
+};
+RcclApi g_rccl;
+std::once_flag g_rccl_once;
+const RcclApi& rccl_api() {
+  std::call_once(g_rccl_once, []() {
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return;
+    g_rccl.comm_init_all = (int (*)(comm_t*, int, const int*))dlsym(lib, "ncclCommInitAll");
+    g_rccl.reduce = (int (*)(const void*, void*, size_t, int, int, int, comm_t, hipStream_t))dlsym(lib, "ncclReduce");
+    g_rccl.group_start = (int (*)(void))dlsym(lib, "ncclGroupStart");
+    g_rccl.group_end = (int (*)(void))dlsym(lib, "ncclGroupEnd");
+    g_rccl.comm_destroy = (int (*)(comm_t))dlsym(lib, "ncclCommDestroy");
+    g_rccl.ok = g_rccl.comm_init_all && g_rccl.reduce && g_rccl.group_start && g_rccl.group_end && g_rccl.comm_destroy;
+  });
+  return g_rccl;
+}
+
+// Communicators are kept per list of devices: creating them takes hundreds of milliseconds, a
+// reduce of a 1080p film about one.  They go when the last context of the process is destroyed.
+struct CommSet {
+  std::vector<int> devices;
+  std::vector<comm_t> comms;
+};
+std::mutex g_comm_mutex;           // also serialises reduces: a communicator runs one collective at a time
+std::vector<CommSet> g_comm_sets;
+void destroy_comm_sets() {
+  std::lock_guard<std::mutex> lock(g_comm_mutex);
+  for (CommSet& set : g_comm_sets)
+    for (size_t i = 0; i < set.comms.size(); ++i) {
+      (void)hipSetDevice(set.devices[i]);
+      g_rccl.comm_destroy(set.comms[i]);
+    }
+  g_comm_sets.clear();
+}
+
+int film_reduce_impl(rrt_ctx** ctxs, int n, int root) {
+  const RcclApi& api = rccl_api();
+  if (!api.ok) return fail(ctxs[root], RRT_E_UNSUPPORTED, "librccl.so not found or incomplete");
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j)
+      if (devs[i] == devs[j]) return fail(ctxs[i], RRT_E_INVALID, "two contexts on one device: one rank per GPU");
+  std::lock_guard<std::mutex> lock(g_comm_mutex);
+  CommSet* set = nullptr;
+  for (CommSet& s : g_comm_sets)
+    if (s.devices == devs) set = &s;
+  if (!set) {
+    CommSet fresh;
+    fresh.devices = devs;
+    fresh.comms.assign(n, nullptr);
+    if (api.comm_init_all(fresh.comms.data(), n, devs.data()) != 0) return fail(ctxs[root], RRT_E_DEVICE, "ncclCommInitAll failed");
+    g_comm_sets.push_back(std::move(fresh));
+    set = &g_comm_sets.back();
+  }
+  const size_t count = (size_t)ctxs[0]->film_w * ctxs[0]->film_h * 4;
+  const int kFloat32 = 7, kSum = 0;  // ncclFloat32, ncclSum (nccl.h: ncclDataType_t, ncclRedOp_t)
+  int rc = RRT_OK;
+  api.group_start();
+  for (int i = 0; i < n; ++i) {
+    (void)hipSetDevice(ctxs[i]->device);
+    if (api.reduce(ctxs[i]->d_film, ctxs[i]->d_film, count, kFloat32, kSum, root, set->comms[i], ctxs[i]->stream) != 0) rc = RRT_E_DEVICE;
+  }
+  if (api.group_end() != 0) rc = RRT_E_DEVICE;
+  // the first-hit buffers as well, when every context keeps them
+  bool all_aovs = true;
+  for (int i = 0; i < n; ++i)
+    all_aovs = all_aovs && ctxs[i]->aovs && ctxs[i]->d_aov && ctxs[i]->aov_w == ctxs[0]->film_w && ctxs[i]->aov_h == ctxs[0]->film_h;
+  if (all_aovs && rc == RRT_OK) {
+    api.group_start();
+    for (int i = 0; i < n; ++i) {
+      (void)hipSetDevice(ctxs[i]->device);
+      if (api.reduce(ctxs[i]->d_aov, ctxs[i]->d_aov, 2 * count, kFloat32, kSum, root, set->comms[i], ctxs[i]->stream) != 0) rc = RRT_E_DEVICE;
+    }
+    if (api.group_end() != 0) rc = RRT_E_DEVICE;
+  }
+  for (int i = 0; i < n; ++i) {
+    (void)hipSetDevice(ctxs[i]->device);
+    if (hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) rc = RRT_E_DEVICE;
+  }
+  if (rc != RRT_OK) return fail(ctxs[root], rc, "ncclReduce failed");
+  return RRT_OK;
+}
+}  // namespace
+}  // extern "C++"
+
 int rrt_film_reduce(rrt_ctx** ctxs, int n, int root) {
   if (!ctxs || n <= 0 || root < 0 || root >= n) return fail(nullptr, RRT_E_INVALID, "bad reduce arguments");
   for (int i = 0; i < n; ++i)
@@ -1299,54 +1400,11 @@ int rrt_film_reduce(rrt_ctx** ctxs, int n, int root) {
     if (ctxs[i]->film_w != ctxs[0]->film_w || ctxs[i]->film_h != ctxs[0]->film_h)
       return fail(ctxs[i], RRT_E_INVALID, "films differ in size");
   if (n == 1) return RRT_OK;
-  typedef void* comm_t;
-  typedef int (*comm_init_all_t)(comm_t*, int, const int*);
-  typedef int (*reduce_t)(const void*, void*, size_t, int, int, int, comm_t, hipStream_t);
-  typedef int (*group_t)(void);
-  typedef int (*comm_destroy_t)(comm_t);
-  static void* lib = nullptr;
-  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) return fail(ctxs[root], RRT_E_UNSUPPORTED, "librccl.so not found");
-  auto init_all = (comm_init_all_t)dlsym(lib, "ncclCommInitAll");
-  auto reduce = (reduce_t)dlsym(lib, "ncclReduce");
-  auto group_start = (group_t)dlsym(lib, "ncclGroupStart");
-  auto group_end = (group_t)dlsym(lib, "ncclGroupEnd");
-  auto comm_destroy = (comm_destroy_t)dlsym(lib, "ncclCommDestroy");
-  if (!init_all || !reduce || !group_start || !group_end || !comm_destroy)
-    return fail(ctxs[root], RRT_E_UNSUPPORTED, "RCCL symbols missing");
-  std::vector<int> devs(n);
-  for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
-  std::vector<comm_t> comms(n);
-  if (init_all(comms.data(), n, devs.data()) != 0) return fail(ctxs[root], RRT_E_DEVICE, "ncclCommInitAll failed");
-  const size_t count = (size_t)ctxs[0]->film_w * ctxs[0]->film_h * 4;
-  int rc = RRT_OK;
-  group_start();
-  for (int i = 0; i < n; ++i) {
-    (void)hipSetDevice(ctxs[i]->device);
-    // ncclFloat32 = 7, ncclSum = 0
-    if (reduce(ctxs[i]->d_film, ctxs[i]->d_film, count, 7, 0, root, comms[i], ctxs[i]->stream) != 0) rc = RRT_E_DEVICE;
+  try {
+    return film_reduce_impl(ctxs, n, root);
+  } catch (...) {
+    return RRT_E_NOMEM;
   }
-  group_end();
-  // the first-hit buffers as well, when every context keeps them
-  bool all_aovs = true;
-  for (int i = 0; i < n; ++i)
-    all_aovs = all_aovs && ctxs[i]->aovs && ctxs[i]->d_aov && ctxs[i]->aov_w == ctxs[0]->film_w && ctxs[i]->aov_h == ctxs[0]->film_h;
-  if (all_aovs && rc == RRT_OK) {
-    group_start();
-    for (int i = 0; i < n; ++i) {
-      (void)hipSetDevice(ctxs[i]->device);
-      if (reduce(ctxs[i]->d_aov, ctxs[i]->d_aov, 2 * count, 7, 0, root, comms[i], ctxs[i]->stream) != 0) rc = RRT_E_DEVICE;
-    }
-    group_end();
-  }
-  for (int i = 0; i < n; ++i) {
-    (void)hipSetDevice(ctxs[i]->device);
-    (void)hipStreamSynchronize(ctxs[i]->stream);
-    comm_destroy(comms[i]);
-  }
-  if (rc != RRT_OK) return fail(ctxs[root], rc, "ncclReduce failed");
-  return RRT_OK;
 }
 
 // Test hook, not part of include/rrt.h: after `n` more host threads every further thread creation of

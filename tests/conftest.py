@@ -53,3 +53,29 @@ def gpu_ctx(rrt):
     ctx = rrt.Context(0)
     yield ctx
     ctx.close()
+
+
+# Achieved parity figures (agreement rates, error maxima, relMSE ...): tests record them here and the
+# session writes them to one JSON next to the GPU run's other outputs, so that the numbers behind
+# "passed" are kept and not only the thresholds.
+PARITY_FIGURES = {}
+
+
+@pytest.fixture(scope="session")
+def parity_record():
+    def record(test, **figures):
+        PARITY_FIGURES.setdefault(test, {}).update({k: (float(v) if hasattr(v, "__float__") else v) for k, v in figures.items()})
+    return record
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not PARITY_FIGURES:
+        return
+    import json
+    path = os.environ.get("RRT_PARITY_JSON") or os.path.join(ROOT, "gpurun_out", "parity.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(PARITY_FIGURES, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

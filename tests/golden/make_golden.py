@@ -38,6 +38,40 @@ def film_fixture(name, scene_desc, rs, w, h, spp, depth, seed):
     print(name, film.shape, "mean radiance", film[..., :3].sum() / film[..., 3].sum())
 
 
+def converged_fixture(name, scene_desc, rs, w, h, crop, spp, seeds):
+    """High-spp oracle films of a crop window, one per seed: what the converged-image test compares the
+    device with (same seed: same random numbers; the second seed gives the oracle's own noise level)."""
+    orc = ob.Oracle(scene_desc)
+    orc.set_camera(rr.Camera.from_settings(rs, w, h))
+    x0, y0, x1, y1 = crop
+    films = {}
+    for seed in seeds:
+        s = rr.make_settings(w, h, rs.depth_limit, rs.clamp, seed=seed, crop=crop)
+        film, st = orc.render(s, 0, spp, threads=8, bucket=(16, 16))
+        films["seed%d" % seed] = film[y0:y1, x0:x1].copy()
+        print(name, "seed", seed, "%.0f paths/s" % (st.paths / st.seconds), "mean", film[..., :3].sum() / film[..., 3].sum())
+    np.savez_compressed(os.path.join(HERE, name), width=w, height=h, crop=np.array(crop), spp=spp, depth=rs.depth_limit,
+                        clamp=rs.clamp, seeds=np.array(seeds), **films)
+
+
+def bench_mesh_fixture(name, n_primary, seed):
+    """First hits and any-hit answers on the full-size bench mesh (the 1,087,716-triangle stand-in of
+    bench.py, scenes/buddha lights and camera): the oracle takes its time to build over a million
+    triangles, so its answers are committed."""
+    scene, rs = scenes_util.buddha_scene(rr, 966, 563)
+    assert scene.desc().n_tris == 1087716
+    orc = ob.Oracle(scene.desc())
+    rays = scenes_util.ray_set(rr, orc, rs, n_primary, seed)
+    prim, t, margin = orc.intersect(rays, with_margin=True)
+    rng = np.random.default_rng(seed)
+    tmax = rng.uniform(0.02, 3.0, size=len(rays))
+    odt = np.concatenate([rays, tmax[:, None]], axis=1).astype(np.float32).astype(np.float64)
+    occluded = orc.occluded(odt)
+    np.savez_compressed(os.path.join(HERE, name), rays=rays.astype(np.float32), prim=prim, t=t, margin=margin,
+                        tmax=odt[:, 6].astype(np.float32), occluded=occluded)
+    print(name, rays.shape, "hits", (prim >= 0).sum(), "clear", (margin >= 1e-4).sum(), "occluded", occluded.sum())
+
+
 def main():
     folder = os.path.join(rr.SCENES, "cornell")
     cornell = rr.Scene.load_from_folder(folder)
@@ -48,6 +82,12 @@ def main():
     mixed, mrs, _ = scenes_util.mixed_scene(rr)
     rays_fixture("mixed_rays.npz", mixed.desc(), mrs, 1200, 2)
     film_fixture("mixed_film_80x60_4spp_seed4.npy", mixed.desc(), mrs, 80, 60, 4, mrs.depth_limit, 4)
+
+    if "--large" in sys.argv:  # minutes of CPU: the converged crops and the full-size bench mesh
+        converged_fixture("cornell_converged_64x64_1024spp.npz", cornell.desc(), crs, 256, 256, (96, 112, 160, 176), 1024, (31, 32))
+        buddha, brs = scenes_util.buddha_scene(rr)
+        converged_fixture("buddha68k_converged_64x64_1024spp.npz", buddha.desc(), brs, 480, 270, (216, 100, 280, 164), 1024, (41, 42))
+        bench_mesh_fixture("bench_mesh_rays.npz", 3000, 7)
 
 
 if __name__ == "__main__":

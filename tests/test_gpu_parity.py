@@ -26,7 +26,7 @@ def mixed(rrt):
     return scenes_util.mixed_scene(rrt)
 
 
-def _check_first_hit(ctx, rays, ref_prim, ref_t, margin):
+def _check_first_hit(ctx, rays, ref_prim, ref_t, margin, record=None, name=None):
     dev_prim, dev_t = ctx.intersect(rays)
     clear = margin >= 1e-4
     assert clear.mean() > 0.95
@@ -42,35 +42,47 @@ def _check_first_hit(ctx, rays, ref_prim, ref_t, margin):
     worst = np.argmax(err / scale)
     print("worst ray: object %d, t %.6g, error %.3g" % (ref_prim[hit][worst], ref_t[hit][worst], err[worst]))
     assert (err <= 1e-5 * scale).all(), (err / scale).max()
+    aside_agree = float((dev_prim[~clear] == ref_prim[~clear]).mean()) if (~clear).any() else 1.0
+    # Rays set aside as ambiguous (within 1e-4 of an edge, grazing, or with a second candidate within 1e-4 of
+    # the first) may legitimately pick the neighbouring triangle, but hit-or-miss must still agree on nearly
+    # all of them and most ids do: a traversal bug would show here first.
     if (~clear).any():
-        print("set aside: %d rays, agreement on them %.3f" % ((~clear).sum(), (dev_prim[~clear] == ref_prim[~clear]).mean()))
+        same_kind = ((dev_prim[~clear] >= 0) == (ref_prim[~clear] >= 0)).mean()
+        print("set aside: %d rays, id agreement on them %.3f, hit/miss agreement %.3f" % ((~clear).sum(), aside_agree, same_kind))
+        assert same_kind >= 0.9, same_kind
+        if (~clear).sum() >= 20:
+            assert aside_agree >= 0.5, aside_agree
+    if record is not None:
+        record(name, rays=int(len(ref_prim)), clear_rays=int(clear.sum()), set_aside=int((~clear).sum()),
+               set_aside_id_agreement=aside_agree, id_agreement_clear=1.0, t_max_rel_err=float(rel.max()),
+               t_max_err_over_scale=float((err / scale).max()))
 
 
-def test_first_hit_cornell_golden(cornell, gpu_ctx):
+def test_first_hit_cornell_golden(cornell, gpu_ctx, parity_record):
     """Fixed ray set with committed oracle answers."""
     g = np.load(os.path.join(GOLDEN, "cornell_rays.npz"))
     gpu_ctx.upload_scene(cornell[0])
-    _check_first_hit(gpu_ctx, g["rays"], g["prim"], g["t"], g["margin"])
+    _check_first_hit(gpu_ctx, g["rays"], g["prim"], g["t"], g["margin"], parity_record, "first_hit_cornell_golden")
 
 
-def test_first_hit_mixed_golden(mixed, gpu_ctx):
+def test_first_hit_mixed_golden(mixed, gpu_ctx, parity_record):
     """Triangles, quad, plane and spheres in one scene."""
     g = np.load(os.path.join(GOLDEN, "mixed_rays.npz"))
     gpu_ctx.upload_scene(mixed[0])
-    _check_first_hit(gpu_ctx, g["rays"], g["prim"], g["t"], g["margin"])
+    _check_first_hit(gpu_ctx, g["rays"], g["prim"], g["t"], g["margin"], parity_record, "first_hit_mixed_golden")
     kinds = set(np.digitize(g["prim"][g["prim"] >= 0], [994, 995, 996]))  # triangles | quad | plane | spheres
     # the light quad lies in the plane y = 5: its box is flat, and under the strict box test (the
     # default reading of the reference's pre-filter) no ray ever finds it
     assert kinds == {0, 2, 3}
 
 
-def test_first_hit_cornell_live(rrt, oracle_binding, cornell, gpu_ctx):
+def test_first_hit_cornell_live(rrt, oracle_binding, cornell, gpu_ctx, parity_record):
     scene, rs = cornell
     orc = oracle_binding.Oracle(scene.desc())
     gpu_ctx.upload_scene(scene)
     rays = scenes_util.ray_set(rrt, orc, rs, 4000, 17)
     ref_prim, ref_t, margin = orc.intersect(rays, with_margin=True)
-    _check_first_hit(gpu_ctx, rays, ref_prim, ref_t, margin)
+    _check_first_hit(gpu_ctx, rays, ref_prim, ref_t, margin, parity_record, "first_hit_cornell_live")
 
 
 @pytest.mark.parametrize("which", ["cornell", "mixed"])
@@ -98,7 +110,7 @@ def buddha(rrt):
     return scenes_util.buddha_scene(rrt)
 
 
-def test_first_hit_and_occlusion_deep_tree(rrt, oracle_binding, buddha, gpu_ctx):
+def test_first_hit_and_occlusion_deep_tree(rrt, oracle_binding, buddha, gpu_ctx, parity_record):
     """68 k triangles: traversal stacks spill past their LDS part, leaves of up to 4 triangles,
     rays leaving the surface in all directions."""
     scene, rs = buddha
@@ -107,7 +119,7 @@ def test_first_hit_and_occlusion_deep_tree(rrt, oracle_binding, buddha, gpu_ctx)
     gpu_ctx.upload_scene(scene)
     rays = scenes_util.ray_set(rrt, orc, rs, 6000, 23)
     ref_prim, ref_t, margin = orc.intersect(rays, with_margin=True)
-    _check_first_hit(gpu_ctx, rays, ref_prim, ref_t, margin)
+    _check_first_hit(gpu_ctx, rays, ref_prim, ref_t, margin, parity_record, "first_hit_buddha68k_live")
     rng = np.random.default_rng(5)
     tmax = rng.uniform(0.02, 2.0, size=len(rays))
     odt = np.concatenate([rays, tmax[:, None]], axis=1).astype(np.float32).astype(np.float64)
@@ -120,7 +132,7 @@ def test_first_hit_and_occlusion_deep_tree(rrt, oracle_binding, buddha, gpu_ctx)
 
 
 @pytest.mark.parametrize("depth", [2, 12])
-def test_per_path_radiance_buddha(rrt, oracle_binding, buddha, gpu_ctx, depth):
+def test_per_path_radiance_buddha(rrt, oracle_binding, buddha, gpu_ctx, depth, parity_record):
     """The bench workload's scene at small size: environment light with MIS escape rays, distant
     light, three area lights, thin lens, microfacet plastic; 2 samples per pixel so that every slot
     starts a second path after its first."""
@@ -151,11 +163,12 @@ def test_per_path_radiance_buddha(rrt, oracle_binding, buddha, gpu_ctx, depth):
     rel = np.abs(both[..., :3] - ref_both[..., :3]).sum() / ref_both[..., :3].sum()
     print("depth %d: per-path agreement %s; two-sample film rel diff %.3g; surface hits per path %.2f" % (
         depth, ["%.4f" % a for a in agree], rel, st.path_bounces / st.paths))
+    parity_record("per_path_buddha68k_depth%d" % depth, path_agreement_min=min(agree), two_sample_film_rel_diff=rel)
     assert min(agree) >= 0.998
     assert rel <= 1e-3
 
 
-def test_stress_scene(rrt, oracle_binding, gpu_ctx):
+def test_stress_scene(rrt, oracle_binding, gpu_ctx, parity_record):
     """24 cow / lamp / teapot trios (375 k triangles, generated normals, many separate objects),
     depth limit 16: first hits, and per-path radiance with the distant and the area light."""
     _, (scene, cam_args, depth, clamp) = scenes_util.stress_scene(rrt, 24, grid=(4, 3, 2))
@@ -172,7 +185,7 @@ def test_stress_scene(rrt, oracle_binding, gpu_ctx):
     sec = scenes_util.bounce_rays(orc, primary, rng)
     rays = np.concatenate([primary, sec]).astype(np.float32).astype(np.float64)
     ref_prim, ref_t, margin = orc.intersect(rays, with_margin=True)
-    _check_first_hit(gpu_ctx, rays, ref_prim, ref_t, margin)
+    _check_first_hit(gpu_ctx, rays, ref_prim, ref_t, margin, parity_record, "first_hit_stress24")
     s = rrt.make_settings(w, h, depth, clamp, seed=4)
     gpu_ctx.film_alloc(w, h)
     gpu_ctx.render(s, 0, 1)
@@ -181,6 +194,7 @@ def test_stress_scene(rrt, oracle_binding, gpu_ctx):
     close = _path_agreement(dev, ref)
     print("stress scene: %.4f of paths agree; %.2f surface hits per path; mean ref %.5f dev %.5f" % (
         close.mean(), st.path_bounces / st.paths, ref[..., :3].mean(), dev[..., :3].mean()))
+    parity_record("per_path_stress24", path_agreement=close.mean(), hits_per_path=st.path_bounces / st.paths)
     assert st.path_bounces / st.paths > 0.5
     assert close.mean() >= 0.998
 
@@ -201,7 +215,7 @@ def _path_agreement(dev, ref):
 
 
 @pytest.mark.parametrize("depth", [1, 2, 8])
-def test_per_path_radiance_cornell(rrt, oracle_binding, cornell, gpu_ctx, depth):
+def test_per_path_radiance_cornell(rrt, oracle_binding, cornell, gpu_ctx, depth, parity_record):
     """One sample per pixel: the film holds each path's radiance."""
     scene, rs = cornell
     dev, cam, s = _device_film(rrt, gpu_ctx, scene, rs, 96, 96, 1, depth, 3)
@@ -211,12 +225,13 @@ def test_per_path_radiance_cornell(rrt, oracle_binding, cornell, gpu_ctx, depth)
     np.testing.assert_array_equal(dev[..., 3], ref[..., 3])
     close = _path_agreement(dev, ref)
     print("depth %d: %.4f of paths agree; mean ref %.5f dev %.5f" % (depth, close.mean(), ref[..., :3].mean(), dev[..., :3].mean()))
+    parity_record("per_path_cornell_depth%d" % depth, path_agreement=close.mean())
     assert close.mean() >= 0.999
     assert ref[..., :3].mean() > 0
 
 
 @pytest.mark.parametrize("depth", [1, 3, 6])
-def test_per_path_radiance_mixed(rrt, oracle_binding, mixed, gpu_ctx, depth):
+def test_per_path_radiance_mixed(rrt, oracle_binding, mixed, gpu_ctx, depth, parity_record):
     """All shape, material and light kinds, thin-lens camera."""
     scene, rs, _ = mixed
     dev, cam, s = _device_film(rrt, gpu_ctx, scene, rs, 120, 90, 1, depth, 5)
@@ -226,6 +241,7 @@ def test_per_path_radiance_mixed(rrt, oracle_binding, mixed, gpu_ctx, depth):
     np.testing.assert_array_equal(dev[..., 3], ref[..., 3])
     close = _path_agreement(dev, ref)
     print("depth %d: %.4f of paths agree; mean ref %.5f dev %.5f" % (depth, close.mean(), ref[..., :3].mean(), dev[..., :3].mean()))
+    parity_record("per_path_mixed_depth%d" % depth, path_agreement=close.mean())
     assert close.mean() >= 0.998
 
 
@@ -611,3 +627,188 @@ def test_stats_count_what_happened(rrt, cornell, gpu_ctx):
     assert 0 < st.path_bounces <= st.rays_extend
     assert 0 < st.rays_shadow <= st.path_bounces
     assert st.bvh_nodes > 4014 // 12 and st.bvh_bytes > 4014 * 96
+
+
+def test_film_reduce_single_process(rrt, cornell, gpu_ctx):
+    """rrt_film_reduce (one context per GPU in one process, RCCL): disjoint sample ranges on two GPUs sum to
+    the film of the whole range, first-hit buffers included, twice in a row (the second call reuses the
+    cached communicators).  With one GPU only the argument checks and the one-context case can run."""
+    scene, rs = cornell
+    w = h = 64
+    cam = rrt.Camera.from_settings(rs, w, h)
+    s = rrt.make_settings(w, h, 4, rs.clamp, seed=21)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    gpu_ctx.render(s, 0, 6)
+    whole = gpu_ctx.film_download()
+    rrt.film_reduce([gpu_ctx], 0)  # one context: nothing to do
+    np.testing.assert_array_equal(gpu_ctx.film_download(), whole)
+    with pytest.raises(rrt.RrtError):
+        rrt.film_reduce([gpu_ctx, gpu_ctx], 0)  # two ranks on one device
+    with pytest.raises(rrt.RrtError):
+        rrt.film_reduce([gpu_ctx], 1)
+    if rrt.hip_lib().rrt_device_count() < 2:
+        pytest.skip("one GPU: the two-rank reduce cannot run here")
+    other = rrt.Context(1)
+    try:
+        other.upload_scene(scene)
+        other.set_camera(cam)
+        other.film_alloc(w, h)
+        for ctx in (gpu_ctx, other):
+            ctx.set_option(rrt.OPT_AOVS, 1)
+        for rounds in range(2):
+            gpu_ctx.film_clear()
+            other.film_clear()
+            gpu_ctx.render(s, 0, 3)
+            other.render(s, 3, 6)
+            a, b = gpu_ctx.film_download(), other.film_download()
+            (an, aa), (bn, ba) = gpu_ctx.aov_download(), other.aov_download()
+            rrt.film_reduce([gpu_ctx, other], 0)
+            np.testing.assert_allclose(gpu_ctx.film_download(), a + b, rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(gpu_ctx.film_download(), whole, rtol=1e-5, atol=1e-6)
+            rn, ra = gpu_ctx.aov_download()
+            np.testing.assert_allclose(rn, an + bn, rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(ra, aa + ba, rtol=1e-6, atol=1e-7)
+    finally:
+        gpu_ctx.set_option(rrt.OPT_AOVS, 0)
+        other.close()
+
+
+def test_first_hit_and_occlusion_bench_mesh_golden(rrt, gpu_ctx, parity_record):
+    """The full-size bench mesh (1,087,716 triangles, what bench.py renders): first hits and any-hit answers
+    against the oracle's, committed as a golden file (tests/golden/make_golden.py --large)."""
+    g = np.load(os.path.join(GOLDEN, "bench_mesh_rays.npz"))
+    scene, _ = scenes_util.buddha_scene(rrt, 966, 563)
+    assert scene.desc().n_tris == 1087716
+    gpu_ctx.upload_scene(scene)
+    rays = g["rays"].astype(np.float64)
+    _check_first_hit_small(gpu_ctx, rays, g["prim"], g["t"], g["margin"], parity_record, "first_hit_bench_mesh_golden")
+    odt = np.concatenate([rays, g["tmax"][:, None].astype(np.float64)], axis=1)
+    dev = gpu_ctx.occluded(odt)
+    near = (g["prim"] >= 0) & (np.abs(g["t"] - odt[:, 6]) <= 1e-4 * odt[:, 6])
+    ok = (g["margin"] >= 1e-4) & ~near
+    np.testing.assert_array_equal(dev[ok], g["occluded"][ok])
+    assert g["occluded"][ok].sum() > 100 and (g["occluded"][ok] == 0).sum() > 100
+    parity_record("occluded_bench_mesh_golden", rays=int(ok.sum()), agreement=float((dev[ok] == g["occluded"][ok]).mean()))
+
+
+def _check_first_hit_small(ctx, rays, ref_prim, ref_t, margin, record, name):
+    """_check_first_hit for ray sets in which most camera rays miss (the bench frame): fewer hits are required."""
+    dev_prim, dev_t = ctx.intersect(rays)
+    clear = margin >= 1e-4
+    assert clear.mean() > 0.95 and (ref_prim[clear] >= 0).sum() > 500
+    np.testing.assert_array_equal(dev_prim[clear], ref_prim[clear])
+    hit = clear & (ref_prim >= 0)
+    err = np.abs(dev_t[hit] - ref_t[hit])
+    scale = np.maximum(ref_t[hit], np.abs(rays[hit, :3]).max(axis=1))
+    assert (err <= 1e-5 * scale).all(), (err / scale).max()
+    record(name, rays=int(len(rays)), clear_rays=int(clear.sum()), hits=int(hit.sum()), id_agreement_clear=1.0,
+           t_max_err_over_scale=float((err / scale).max()))
+
+
+def _rel_mse(a, b, eps=1e-2):
+    """Per-pixel relative mean squared error of image a against b (linear radiance, all channels)."""
+    return float(np.mean((a - b) ** 2 / (b * b + eps)))
+
+
+def _box4_rmse_8bit(rrt, film_a, film_b):
+    """RMSE, in units of one 8-bit code value / 255, between the tone-mapped images after a 4 x 4 box filter."""
+    a = rrt.tonemap(film_a.astype(np.float32)).astype(np.float64) / 255.0
+    b = rrt.tonemap(film_b.astype(np.float32)).astype(np.float64) / 255.0
+    h, w = a.shape[:2]
+    a = a.reshape(h // 4, 4, w // 4, 4, 3).mean(axis=(1, 3))
+    b = b.reshape(h // 4, 4, w // 4, 4, 3).mean(axis=(1, 3))
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+@pytest.mark.parametrize("which", ["cornell", "buddha68k"])
+def test_converged_image(rrt, cornell, buddha, gpu_ctx, parity_record, which):
+    """Converged images at 1024 samples per pixel on a 64 x 64 crop (cornell: the sphere and pillars; buddha:
+    the statue's body), device against oracle films committed as golden files (two seeds each).
+
+    Stated bounds, on the linear per-pixel mean radiance L = sum / weight:
+    * same seed (the device draws the same random numbers as the oracle): relMSE(dev, orc) with eps = 1e-2
+      at most 2 % of the oracle's own seed-to-seed relMSE -- the few paths that take another branch at
+      an f32/f64 tie (0.05-0.2 %) change the image far less than the Monte Carlo noise does -- and the
+      8-bit tone-mapped images after a 4 x 4 box filter differ by an RMSE of at most 0.25/255;
+    * another seed (independent noise): relMSE(dev, orc) <= 2 x the oracle's seed-to-seed relMSE, box-filtered
+      8-bit RMSE <= 2/255, and no bias: the crop's total radiance agrees with the oracle's within 4 standard
+      deviations of the oracle's own seed-to-seed scatter (estimated per pixel from its two films)."""
+    g = np.load(os.path.join(GOLDEN, "%s_converged_64x64_1024spp.npz" % which))
+    scene, rs = cornell if which == "cornell" else buddha
+    w, h, spp = int(g["width"]), int(g["height"]), int(g["spp"])
+    x0, y0, x1, y1 = [int(v) for v in g["crop"]]
+    seed_a, seed_b = [int(v) for v in g["seeds"]]
+    assert int(g["depth"]) == rs.depth_limit and float(g["clamp"]) == rs.clamp
+    orc_a, orc_b = g["seed%d" % seed_a], g["seed%d" % seed_b]
+    assert (orc_a[..., 3] == spp).all() and (orc_b[..., 3] == spp).all()
+    cam = rrt.Camera.from_settings(rs, w, h)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    films = {}
+    for seed in (seed_a, seed_b + 1000):
+        s = rrt.make_settings(w, h, rs.depth_limit, rs.clamp, seed=seed, crop=(x0, y0, x1, y1))
+        gpu_ctx.film_clear()
+        gpu_ctx.render(s, 0, spp)
+        film = gpu_ctx.film_download().astype(np.float64)[y0:y1, x0:x1]
+        assert (film[..., 3] == spp).all()
+        films[seed] = film
+    mean = lambda f: f[..., :3] / f[..., 3:4]
+    la, lb, da, dc = mean(orc_a), mean(orc_b), mean(films[seed_a]), mean(films[seed_b + 1000])
+    noise = _rel_mse(lb, la)
+    same = _rel_mse(da, la)
+    other = _rel_mse(dc, la)
+    rmse_same = _box4_rmse_8bit(rrt, films[seed_a], orc_a)
+    rmse_other = _box4_rmse_8bit(rrt, films[seed_b + 1000], orc_a)
+    rmse_noise = _box4_rmse_8bit(rrt, orc_b, orc_a)
+    # bias test on the crop's total: variance of one film's total ~ sum over pixels of (a - b)^2 / 2
+    sigma_total = np.sqrt(((la - lb) ** 2).sum() / 2.0)
+    z_other = abs(dc.sum() - la.sum()) / (np.sqrt(2.0) * sigma_total)
+    z_same = abs(da.sum() - la.sum()) / (np.sqrt(2.0) * sigma_total)
+    print("%s: relMSE oracle seed-to-seed %.3g, device same seed %.3g (%.4f of it), device other seed %.3g (%.3f of it); "
+          "box-filtered 8-bit RMSE same %.3f/255, other %.3f/255 (oracle's own %.3f/255); total radiance z: other seed %.2f, "
+          "same seed %.3f; mean L oracle %.5f device %.5f" % (which, noise, same, same / noise, other, other / noise,
+                                                            rmse_same * 255, rmse_other * 255, rmse_noise * 255, z_other,
+                                                            z_same, la.mean(), dc.mean()))
+    parity_record("converged_%s" % which, spp=spp, relmse_oracle_seed_to_seed=noise, relmse_device_same_seed=same,
+                  relmse_device_other_seed=other, rmse8_box4_same_seed=rmse_same * 255, rmse8_box4_other_seed=rmse_other * 255,
+                  rmse8_box4_oracle_seed_to_seed=rmse_noise * 255, z_total_other_seed=z_other, z_total_same_seed=z_same,
+                  mean_radiance_oracle=la.mean(), mean_radiance_device_other_seed=dc.mean())
+    assert noise > 0
+    assert same <= 0.02 * noise
+    assert rmse_same * 255 <= 0.25
+    assert other <= 2.0 * noise
+    assert rmse_other * 255 <= 2.0
+    assert z_other <= 4.0
+    assert z_same <= 0.5
+
+
+def test_4k_sample_ranges_compose(rrt, buddha, gpu_ctx, parity_record):
+    """The 3840 x 2160 configuration on one GPU: the sample ranges [0, 512) and [512, 1024) -- what two of the
+    GPUs of a sample-sharded render would take -- add up to the film of [0, 1024) rendered in one call, up to
+    float summation order; every pixel gets every sample."""
+    scene, rs = buddha
+    w, h, spp = 3840, 2160, 1024
+    cam = rrt.Camera.from_settings(rs, w, h)
+    s = rrt.make_settings(w, h, rs.depth_limit, rs.clamp, seed=2)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    gpu_ctx.reset_stats()
+    gpu_ctx.render(s, 0, spp)
+    whole = gpu_ctx.film_download()
+    assert gpu_ctx.stats().paths == w * h * spp
+    assert (whole[..., 3] == spp).all() and np.isfinite(whole).all()
+    gpu_ctx.film_clear()
+    gpu_ctx.render(s, 0, spp // 2)
+    first = gpu_ctx.film_download()
+    assert (first[..., 3] == spp // 2).all()
+    gpu_ctx.render(s, spp // 2, spp)
+    parts = gpu_ctx.film_download()
+    np.testing.assert_array_equal(parts[..., 3], whole[..., 3])
+    diff = np.abs(parts[..., :3].astype(np.float64) - whole[..., :3]).max() / whole[..., :3].max()
+    print("4K: max difference %.3g of the film's maximum" % diff)
+    parity_record("compose_4k_1024spp", max_diff_over_film_max=diff)
+    assert diff <= 1e-5
