@@ -185,6 +185,8 @@ def main():
     ctx.film_bind(film.data_ptr(), W, H)
     stream = torch.cuda.current_stream(device)
     ctx.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    if os.environ.get("RRT_TAIL_PATHS_OVERRIDE"):  # diagnostic: threshold of the tail kernel
+        ctx.set_option(rr.OPT_TAIL_PATHS, int(os.environ["RRT_TAIL_PATHS_OVERRIDE"]))
     if args.max_slots:
         ctx.set_option(rr.OPT_MAX_SLOTS, args.max_slots)
     if args.batch_samples:
@@ -310,7 +312,7 @@ def main():
             "kernel_ms_per_step": {"primary": st.ms_primary / args.steps, "start": st.ms_raygen / args.steps,
                                    "extend": st.ms_extend / args.steps,
                                    "shade": st.ms_shade / args.steps, "connect": st.ms_connect / args.steps,
-                                   "film": st.ms_film / args.steps},
+                                   "film": st.ms_film / args.steps, "tail": st.ms_tail / args.steps},
             "roofline": roofline,
             "traversal_kernels": kernels,
         }

@@ -158,6 +158,8 @@ typedef struct rrt_stats {
   double ms_primary;         /* kernel time of the primary kernels */
   uint64_t launches_primary;
   uint64_t rays_primary;     /* closest-hit queries made by the primary kernels (part of rays_extend) */
+  double ms_tail;            /* kernel time of the tail kernels (RRT_OPT_TAIL_PATHS) */
+  uint64_t launches_tail;
 } rrt_stats;
 
 /* Number of visible HIP devices, or a negative code. */
@@ -270,6 +272,10 @@ enum {
                                   free device memory) */
   RRT_OPT_COUNT_TRAVERSAL = 4, /* 1: count nodes_visited / tris_tested (slower kernels; for calibration runs) */
   RRT_OPT_AOVS = 6,            /* 1: accumulate first-hit normal and albedo (rrt_aov_download); default 0 */
+  RRT_OPT_TAIL_PATHS = 7,      /* once at most this many paths are still alive, one kernel runs each of them to its end
+                                  (continuation ray, shading, visibility rays, next bounce ...) instead of further rounds of
+                                  the separate kernels, each of which would wait for its longest ray; same film.  0: never.
+                                  Default 2^21.  Only with one path slot per sample. */
   RRT_OPT_SIDE_STREAM = 5      /* 1 (default): rrt_render runs the visibility rays of an iteration on a stream of its own
                                   beside the next iteration's closest-hit rays and joins it again before it returns
                                   work to the caller's stream; 0: everything on the one stream (per-kernel times in

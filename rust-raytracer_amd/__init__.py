@@ -73,7 +73,8 @@ class Stats(C.Structure):
                 ("launches_extend", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("bvh_nodes", C.c_uint64), ("bvh_bytes", C.c_uint64),
                 ("nodes_by_kernel", C.c_uint64 * 3), ("tris_by_kernel", C.c_uint64 * 3),
-                ("ms_primary", C.c_double), ("launches_primary", C.c_uint64), ("rays_primary", C.c_uint64)]
+                ("ms_primary", C.c_double), ("launches_primary", C.c_uint64), ("rays_primary", C.c_uint64),
+                ("ms_tail", C.c_double), ("launches_tail", C.c_uint64)]
 
 
 class RenderSettingsFile(C.Structure):
@@ -91,7 +92,7 @@ class RenderSettingsFile(C.Structure):
 MAT_MATTE, MAT_PLASTIC, MAT_MIRROR, MAT_GLASS = 0, 1, 2, 3
 LIGHT_POINT, LIGHT_AREA, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2, 3
 RECT_AABB_STRICT, RECT_AABB_INCLUSIVE, RECT_AABB_OFF = 0, 1, 2
-OPT_TIMING, OPT_BATCH_SAMPLES, OPT_MAX_SLOTS, OPT_COUNT_TRAVERSAL, OPT_SIDE_STREAM, OPT_AOVS = 1, 2, 3, 4, 5, 6
+OPT_TIMING, OPT_BATCH_SAMPLES, OPT_MAX_SLOTS, OPT_COUNT_TRAVERSAL, OPT_SIDE_STREAM, OPT_AOVS, OPT_TAIL_PATHS = 1, 2, 3, 4, 5, 6, 7
 FILTER_NONE, FILTER_GAUSSIAN, FILTER_MITCHELL = 0, 1, 2
 NOALLOC_MAX_RAYS = 65536  # RRT_NOALLOC_MAX_RAYS
 

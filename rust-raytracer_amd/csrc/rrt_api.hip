@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -39,6 +40,12 @@ constexpr uint32_t kMaxSlotsPerPixel = 1024;
 constexpr uint32_t kQueueGridBlocks = 8192;  // 32 blocks per CU for the kernels that walk a queue chunk by chunk
 #ifndef RRT_OVERLAP_FROM
 #define RRT_OVERLAP_FROM 1   // first iteration whose visibility rays run beside the next extend (-1: never)
+#endif
+#ifndef RRT_TAIL_PATHS
+#define RRT_TAIL_PATHS (1u << 21)
+#endif
+#ifndef RRT_TAIL_BURST
+#define RRT_TAIL_BURST 2   // iterations between two looks at the queue lengths while the tail kernel may take over
 #endif
 #ifndef RRT_TRACE_GRID
 #define RRT_TRACE_GRID 2048
@@ -83,7 +90,7 @@ unsigned char* scratch_for_device(int device, std::string* error) {
 
 struct EventPair {
   hipEvent_t begin, end;
-  int stage;  // 0 start, 1 extend, 2 shade, 3 connect, 4 film, 5 primary
+  int stage;  // 0 start, 1 extend, 2 shade, 3 connect, 4 film, 5 primary, 6 tail
 };
 
 }  // namespace
@@ -138,16 +145,18 @@ struct rrt_ctx {
   bool count_traversal = false;
   bool side_stream_allowed = true;            // RRT_OPT_SIDE_STREAM
   bool aovs = false;                          // RRT_OPT_AOVS
+  bool debug_pending = false;                 // RRT_DEBUG_PENDING in the environment: print the queue lengths read back
   float* d_aov = nullptr;                     // [2][film_h][film_w][4]: first-hit normal sums (+ hit count), albedo sums
   uint32_t aov_w = 0, aov_h = 0;
   uint32_t batch_samples = 0;
   uint32_t max_slots = 0;  // 0: sized from the free device memory
+  uint32_t tail_paths = RRT_TAIL_PATHS;  // RRT_OPT_TAIL_PATHS: at most this many live paths go to the tail kernel (0: never)
 
   // timing
   std::vector<EventPair> events;
   size_t events_used = 0;
-  double ms[6] = {0, 0, 0, 0, 0, 0};  // start, extend, shade, connect, film, primary
-  uint64_t launches_extend = 0, launches_primary = 0, rays_primary = 0;
+  double ms[7] = {0, 0, 0, 0, 0, 0, 0};  // start, extend, shade, connect, film, primary, tail
+  uint64_t launches_extend = 0, launches_primary = 0, rays_primary = 0, launches_tail = 0;
 };
 
 namespace {
@@ -387,6 +396,7 @@ int collect_timing(rrt_ctx* ctx) {
     ctx->ms[ctx->events[i].stage] += ms;
     if (ctx->events[i].stage == 1) ctx->launches_extend++;
     if (ctx->events[i].stage == 5) ctx->launches_primary++;
+    if (ctx->events[i].stage == 6) ctx->launches_tail++;
   }
   ctx->events_used = 0;
   return RRT_OK;
@@ -421,6 +431,8 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_connect, hipEventDisableTiming));
   }
   bool connect_outstanding = false;  // a connect on the side stream that the main stream has not joined yet
+  // the tail kernel: one sample per slot only; not while traversal steps are being counted per kernel
+  const bool use_tail = p.single != 0 && ctx->tail_paths > 0 && !ctx->count_traversal;
   // Whichever way the pass is left: the caller's stream waits for a connect still running on the side
   // stream (the next call's kernels rewrite the records it reads), and a pass that failed leaves no
   // half-recorded timing events behind.
@@ -490,11 +502,34 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pending, p.a.counters + row_words * (parity ? kRowStart1 : kRowStart0), row_bytes * 2,
                                 hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    uint64_t pending = 0;
+    uint64_t pending = 0, pending_start = 0;
     for (int i = 0; i < 2 * kSegments; ++i) pending += ctx->h_pending[(size_t)i * kCounterStride];
+    for (int i = 0; i < kSegments; ++i) pending_start += ctx->h_pending[(size_t)i * kCounterStride];  // the start row comes first
+    if (ctx->debug_pending) std::fprintf(stderr, "after iteration %llu: %llu pending (%llu start)\n", (unsigned long long)it, (unsigned long long)pending, (unsigned long long)pending_start);
     if (pending == 0) break;
     if (it >= max_iterations) return fail(ctx, RRT_E_DEVICE, "path queues did not drain");
-    burst = (uint32_t)std::min<uint64_t>(4, max_iterations - it);
+    if (use_tail && pending <= ctx->tail_paths) {
+      // Few paths left: one kernel runs each of them to its end instead of a dozen more iterations that
+      // would each wait for their longest rays (k_tail).  First whatever the last connect still adds, then
+      // the rays that escaped after a specular bounce (they only collect the environment).
+      if (connect_outstanding) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_connect, 0));
+        connect_outstanding = false;
+      }
+      HIP_TRY(ctx, hipMemsetAsync(p.a.counters + row_words * kRowWorkExtend, 0, row_bytes, ctx->stream));
+      if (pending_start) {
+        if ((rc = record_begin(ctx, 0)) != RRT_OK) return rc;
+        hipLaunchKernelGGL(k_start, dim3(grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, parity);
+        if ((rc = record_end(ctx)) != RRT_OK) return rc;
+      }
+      if (pending > pending_start) {
+        if ((rc = record_begin(ctx, 6)) != RRT_OK) return rc;
+        hipLaunchKernelGGL(k_tail<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, parity);
+        if ((rc = record_end(ctx)) != RRT_OK) return rc;
+      }
+      break;
+    }
+    burst = (uint32_t)std::min<uint64_t>(use_tail ? RRT_TAIL_BURST : 4, max_iterations - it);
   }
   if (connect_outstanding) {
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_connect, 0));
@@ -545,6 +580,7 @@ rrt_ctx* rrt_create(int device) {
     return nullptr;
   }
   ctx->device = device;
+  ctx->debug_pending = std::getenv("RRT_DEBUG_PENDING") != nullptr;
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&ctx->d_stats, sizeof(DeviceStats)) != hipSuccess ||
       hipMalloc((void**)&ctx->d_work, sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess) {
@@ -1210,6 +1246,10 @@ int rrt_set_option(rrt_ctx* ctx, int option, int64_t value) {
     case RRT_OPT_COUNT_TRAVERSAL: ctx->count_traversal = value != 0; return RRT_OK;
     case RRT_OPT_SIDE_STREAM: ctx->side_stream_allowed = value != 0; return RRT_OK;
     case RRT_OPT_AOVS: ctx->aovs = value != 0; return RRT_OK;
+    case RRT_OPT_TAIL_PATHS:
+      if (value < 0 || value > (int64_t)kSlotLimit) return fail(ctx, RRT_E_INVALID, "tail paths out of range");
+      ctx->tail_paths = (uint32_t)value;
+      return RRT_OK;
     default: return fail(ctx, RRT_E_INVALID, "unknown option");
   }
 }
@@ -1242,6 +1282,8 @@ int rrt_get_stats(rrt_ctx* ctx, rrt_stats* out) {
   out->ms_connect = ctx->ms[3];
   out->ms_film = ctx->ms[4];
   out->launches_extend = ctx->launches_extend;
+  out->ms_tail = ctx->ms[6];
+  out->launches_tail = ctx->launches_tail;
   out->bvh_nodes = ctx->n_nodes;
   out->bvh_bytes = ctx->bvh_bytes;
 #ifdef RRT_PHASE_CLOCKS
@@ -1290,7 +1332,7 @@ int rrt_reset_stats(rrt_ctx* ctx) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)));
   for (double& m : ctx->ms) m = 0.0;
-  ctx->launches_extend = ctx->launches_primary = ctx->rays_primary = 0;
+  ctx->launches_extend = ctx->launches_primary = ctx->rays_primary = ctx->launches_tail = 0;
   return RRT_OK;
 }
 

@@ -55,6 +55,10 @@
 #define RRT_SHADE_WAVES 4
 #endif
 #define RRT_SHADE_BOUNDS __launch_bounds__(256, RRT_SHADE_WAVES)
+// Lanes of a wave of the tail kernel that must have finished their paths before the wave takes new ones.
+#ifndef RRT_TAIL_QUORUM
+#define RRT_TAIL_QUORUM 32
+#endif
 
 namespace rrt {
 
@@ -610,6 +614,110 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_primary(RenderParams p, Came
 }
 
 // ---------------------------------------------------------------- shade
+// What one bounce of trace() (src/tracer.rs:70-130) leaves to be done: the visibility rays of
+// estimate_direct with the radiance each would add, and the continuation ray.
+struct ShadeOut {
+  uint32_t flags;        // kHasLightRay | kHasMisRay | kClamp
+  V3 light_c;            // contribution of the light sample if its visibility ray gets through
+  V3 sh_o, sh_d;         // that ray
+  float sh_tmax;
+  int sh_skip;           // object code of the sampled light's own quad, or -1
+  V3 mis_o, mis_d, mis_c;  // escape ray of the BSDF-sampling estimator (environment light) and its contribution
+  bool survive;          // the path goes on with (next_o, next_d, next_state) and throughput beta
+  V3 next_o, next_d;
+  uint32_t next_state;
+  V3 beta;
+};
+
+// The body of the bounce loop for a path that hit surface `s` (object `prim`): uniform_sample_light +
+// estimate_direct up to their rays, the continuation sample, throughput, Russian roulette
+// (src/tracer.rs:70-130, 141-283).  Shared by k_shade and k_tail: one path gives the same numbers in both.
+RRT_DEV ShadeOut shade_bounce(const RenderParams& p, const SceneTables* sc, const Surface& s, int prim, uint32_t pixel,
+                              uint32_t sample, uint32_t bounce, V3 beta) {
+  ShadeOut o;
+  o.flags = 0;
+  o.light_c = o.sh_o = o.sh_d = o.mis_o = o.mis_d = o.mis_c = o.next_o = o.next_d = mk(0.0f, 0.0f, 0.0f);
+  o.sh_tmax = 0.0f;
+  o.sh_skip = -1;
+  o.survive = false;
+  o.next_state = 0;
+  const DeviceMaterial m = p.materials[s.material];
+  if (p.aov && bounce == 0) {
+    // what a denoiser wants beside the image: the shading normal and the albedo of what the camera sees
+    float* an = p.aov + 4 * (size_t)pixel;
+    float* aa = an + 4 * (size_t)p.width * p.height;
+    const V3 albedo = m.diffuse_kind != DIFF_NONE ? mk(m.diffuse) : (m.spec_kind != SPEC_NONE ? mk(m.spec) : mk(m.trans));
+    unsafeAtomicAdd(an + 0, s.ns.x); unsafeAtomicAdd(an + 1, s.ns.y); unsafeAtomicAdd(an + 2, s.ns.z);
+    unsafeAtomicAdd(an + 3, 1.0f);
+    unsafeAtomicAdd(aa + 0, albedo.x); unsafeAtomicAdd(aa + 1, albedo.y); unsafeAtomicAdd(aa + 2, albedo.z);
+  }
+  const Rng4 ra = rng_block(p.seed, pixel, sample, 1 + 3 * bounce);
+
+  // ---- uniform_sample_light + estimate_direct (src/tracer.rs:141-283)
+  if (sc->n_lights > 0) {
+    const int li = min((int)(ra.u[0] * (float)sc->n_lights), sc->n_lights - 1);
+    const float n_lights = (float)sc->n_lights;  // division by light_pdf = 1 / n
+    const LightSample ls = sample_light(sc, p.env, li, s.p, ra.u[1], ra.u[2]);
+    if (ls.pdf > 1e-6f && !is_zero(ls.li)) {
+      V3 f;
+      float pdf_s;
+      bsdf_eval(s, m, ls.wi, &f, &pdf_s);
+      f = f * fabsf(dot(ls.wi, s.ns));
+      if (!is_zero(f) && !(prim < sc->n_tris && own_triangle_occludes(p.tris, prim, s, ls.wi))) {
+        const float w = ls.delta ? 1.0f : power_heuristic(ls.pdf, pdf_s);
+        o.light_c = beta * f * ls.li * (w * n_lights / ls.pdf);
+        // check_light_visible (src/renderer.rs:277-295): from the surface point towards the
+        // sample, stopping just short of it.  The 1e-9 / 1e-7 margins of the f64 original do not
+        // exist in f32: the surface being left and the light's own quad are excluded by identity.
+        o.sh_tmax = ls.dist < INFINITY ? ls.dist * (1.0f - 1e-5f) : INFINITY;
+        o.sh_o = s.p;
+        o.sh_d = ls.wi;
+        o.sh_skip = ls.skip;
+        o.flags |= kHasLightRay;
+      }
+    }
+    // BSDF-sampling half of the estimator (src/tracer.rs:204-280).  For an area light it can
+    // only ever add AreaLight::emitting() = 0, so it is not evaluated; for the environment
+    // light it adds the texel along the sampled direction if the ray escapes.
+    if (sc->lights[li].kind == RRT_LIGHT_INFINITE) {
+      const Rng4 rb = rng_block(p.seed, pixel, sample, 2 + 3 * bounce);
+      const BsdfSample bs = bsdf_sample(s, m, rb.u[0], rb.u[1], rb.u[2]);
+      const V3 f = bs.f * fabsf(dot(bs.wi, s.ns));
+      if (!is_zero(f) && bs.pdf > 1e-6f) {
+        const float w = bs.specular ? 1.0f : power_heuristic(bs.pdf, 1.0f);  // pdf_incidence == 1
+        const V3 le = env_lookup(sc, p.env, normalize(bs.wi));
+        if (!is_zero(le)) {
+          o.mis_c = beta * f * le * (w * n_lights / bs.pdf);
+          o.mis_o = offset_ray_origin(s.p, s.ng, bs.wi);
+          o.mis_d = bs.wi;
+          o.flags |= kHasMisRay;
+        }
+      }
+    }
+  }
+
+  // ---- continuation (src/tracer.rs:77-130)
+  const Rng4 rc = rng_block(p.seed, pixel, sample, 3 + 3 * bounce);
+  const BsdfSample bs = bsdf_sample(s, m, rc.u[0], rc.u[1], rc.u[2]);
+  if (!(bs.pdf == 0.0f || is_zero(bs.f))) {
+    beta = beta * (bs.f * (fabsf(dot(bs.wi, s.ns)) / bs.pdf));
+    if (p.clamp > 0.0f) o.flags |= kClamp;  // the clamp comes after this bounce's direct light is in L
+    o.survive = bounce + 1 < p.depth_limit;
+    if (bounce > 3) {
+      const float q = fmaxf(1.0f - vmax(beta), 0.05f);
+      if (ra.u[3] < q) o.survive = false;
+      beta = beta / (1.0f - q);
+    }
+    if (o.survive) {
+      o.next_o = offset_ray_origin(s.p, s.ng, bs.wi);
+      o.next_d = bs.wi;
+      o.next_state = ((bounce + 1) << 1) | (bs.specular ? 1u : 0u);
+    }
+  }
+  o.beta = beta;
+  return o;
+}
+
 __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
   __shared__ uint32_t lens[kSegments + 1];
   // the whole of the small tables in LDS: every lane reads a score of fields of the light it draws
@@ -645,90 +753,30 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
     // AreaLight::emitting is zero (lights/area.rs:23-25): hitting an emitter adds nothing
     const Surface s = prim < sc->n_tris ? surface_triangle(p.tris, p.tri_shade, prim, h4.z, h4.w, dir)
                                         : surface_other(sc, prim, h4.y, mk(p.a.trace[slot].ray_o), dir);
-    const DeviceMaterial m = p.materials[s.material];
-    const uint32_t pixel = y * p.width + x;
-    if (p.aov && bounce == 0) {
-      // what a denoiser wants beside the image: the shading normal and the albedo of what the camera sees
-      float* an = p.aov + 4 * (size_t)pixel;
-      float* aa = an + 4 * (size_t)p.width * p.height;
-      const V3 albedo = m.diffuse_kind != DIFF_NONE ? mk(m.diffuse) : (m.spec_kind != SPEC_NONE ? mk(m.spec) : mk(m.trans));
-      unsafeAtomicAdd(an + 0, s.ns.x); unsafeAtomicAdd(an + 1, s.ns.y); unsafeAtomicAdd(an + 2, s.ns.z);
-      unsafeAtomicAdd(an + 3, 1.0f);
-      unsafeAtomicAdd(aa + 0, albedo.x); unsafeAtomicAdd(aa + 1, albedo.y); unsafeAtomicAdd(aa + 2, albedo.z);
+    const ShadeOut o = shade_bounce(p, sc, s, prim, y * p.width + x, sample, bounce, beta);
+    has_light = (o.flags & kHasLightRay) != 0;
+    has_mis = (o.flags & kHasMisRay) != 0;
+    if (has_light) {
+      p.a.shadow[slot].sh_o = f4(o.sh_o, o.sh_tmax);
+      p.a.shadow[slot].sh_d = f4(o.sh_d, __int_as_float(o.sh_skip));
     }
-    const Rng4 ra = rng_block(p.seed, pixel, sample, 1 + 3 * bounce);
-
-    // ---- uniform_sample_light + estimate_direct (src/tracer.rs:141-283)
-    uint32_t flags = 0;
-    V3 light_c = mk(0.0f, 0.0f, 0.0f);
-    if (sc->n_lights > 0) {
-      const int li = min((int)(ra.u[0] * (float)sc->n_lights), sc->n_lights - 1);
-      const float n_lights = (float)sc->n_lights;  // division by light_pdf = 1 / n
-      const LightSample ls = sample_light(sc, p.env, li, s.p, ra.u[1], ra.u[2]);
-      if (ls.pdf > 1e-6f && !is_zero(ls.li)) {
-        V3 f;
-        float pdf_s;
-        bsdf_eval(s, m, ls.wi, &f, &pdf_s);
-        f = f * fabsf(dot(ls.wi, s.ns));
-        if (!is_zero(f) && !(prim < sc->n_tris && own_triangle_occludes(p.tris, prim, s, ls.wi))) {
-          const float w = ls.delta ? 1.0f : power_heuristic(ls.pdf, pdf_s);
-          light_c = beta * f * ls.li * (w * n_lights / ls.pdf);
-          // check_light_visible (src/renderer.rs:277-295): from the surface point towards the
-          // sample, stopping just short of it.  The 1e-9 / 1e-7 margins of the f64 original do not
-          // exist in f32: the surface being left and the light's own quad are excluded by identity.
-          const float tmax = ls.dist < INFINITY ? ls.dist * (1.0f - 1e-5f) : INFINITY;
-          p.a.shadow[slot].sh_o = f4(s.p, tmax);
-          p.a.shadow[slot].sh_d = f4(ls.wi, __int_as_float(ls.skip));
-          flags |= kHasLightRay;
-          has_light = true;
-        }
-      }
-      // BSDF-sampling half of the estimator (src/tracer.rs:204-280).  For an area light it can
-      // only ever add AreaLight::emitting() = 0, so it is not evaluated; for the environment
-      // light it adds the texel along the sampled direction if the ray escapes.
-      if (sc->lights[li].kind == RRT_LIGHT_INFINITE) {
-        const Rng4 rb = rng_block(p.seed, pixel, sample, 2 + 3 * bounce);
-        const BsdfSample bs = bsdf_sample(s, m, rb.u[0], rb.u[1], rb.u[2]);
-        const V3 f = bs.f * fabsf(dot(bs.wi, s.ns));
-        if (!is_zero(f) && bs.pdf > 1e-6f) {
-          const float w = bs.specular ? 1.0f : power_heuristic(bs.pdf, 1.0f);  // pdf_incidence == 1
-          const V3 le = env_lookup(sc, p.env, normalize(bs.wi));
-          if (!is_zero(le)) {
-            const V3 c = beta * f * le * (w * n_lights / bs.pdf);
-            p.a.mis[slot].mis_o = f4(offset_ray_origin(s.p, s.ng, bs.wi), 0.0f);
-            p.a.mis[slot].mis_d = f4(bs.wi, 0.0f);
-            p.a.mis[slot].mis_c = f4(c, 0.0f);
-            flags |= kHasMisRay;
-            has_mis = true;
-          }
-        }
-      }
+    if (has_mis) {
+      p.a.mis[slot].mis_o = f4(o.mis_o, 0.0f);
+      p.a.mis[slot].mis_d = f4(o.mis_d, 0.0f);
+      p.a.mis[slot].mis_c = f4(o.mis_c, 0.0f);
     }
-
-    // ---- continuation (src/tracer.rs:77-130)
-    const Rng4 rc = rng_block(p.seed, pixel, sample, 3 + 3 * bounce);
-    const BsdfSample bs = bsdf_sample(s, m, rc.u[0], rc.u[1], rc.u[2]);
-    if (!(bs.pdf == 0.0f || is_zero(bs.f))) {
-      beta = beta * (bs.f * (fabsf(dot(bs.wi, s.ns)) / bs.pdf));
-      if (p.clamp > 0.0f) flags |= kClamp;  // the clamp comes after this bounce's direct light is in L
-      survive = bounce + 1 < p.depth_limit;
-      if (bounce > 3) {
-        const float q = fmaxf(1.0f - vmax(beta), 0.05f);
-        if (ra.u[3] < q) survive = false;
-        beta = beta / (1.0f - q);
-      }
-      if (survive) {
-        next_o = offset_ray_origin(s.p, s.ng, bs.wi);
-        next_d = bs.wi;
-        next_state = ((bounce + 1) << 1) | (bs.specular ? 1u : 0u);
-        p.a.trace[slot].beta = f4(beta, 0.0f);
-      }
+    survive = o.survive;
+    if (survive) {
+      next_o = o.next_o;
+      next_d = o.next_d;
+      next_state = o.next_state;
+      p.a.trace[slot].beta = f4(o.beta, 0.0f);
     }
-    has_work = (flags & (kHasLightRay | kHasMisRay)) != 0;
+    has_work = has_light || has_mis;
     // without pending light the running sum is unchanged since its last clamp: nothing to do
     // the record carries the object the rays leave: connect must not read hit[], which the next
     // extend may already be overwriting for this slot
-    if (has_work) p.a.shadow[slot].sh_c = f4(light_c, __uint_as_float(flags | ((uint32_t)prim << 3)));
+    if (has_work) p.a.shadow[slot].sh_c = f4(o.light_c, __uint_as_float(o.flags | ((uint32_t)prim << 3)));
   }
   ray_queue_push(p, p.a.rays_cont[next], row_cont(next), chunk, survive, slot, next_o, next_d, next_state);
   queue_push(p, p.a.q_start[next], row_start(next), chunk, active && !survive && !p.single, slot);
@@ -836,6 +884,213 @@ __global__ void RRT_TRACE_BOUNDS k_connect(RenderParams p) {
   trace_stream<true, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkConnect, 0),
                             queue_blocks(longest, grab), RRT_REFILL_QUORUM, job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, 2, ctr);
+}
+
+// ---------------------------------------------------------------- tail
+// The last iterations of a pass hold few paths, and each of their launches waits for its longest
+// ray: a dozen launches of start / extend / shade / connect that each take a fraction of a millisecond
+// whatever the number of rays.  Once few paths are left the host hands ALL remaining work to this
+// one kernel instead: a job is a path, and a lane runs it to its end -- continuation ray, shading,
+// the visibility rays of that bounce, clamp, next continuation ray -- through the same traversal
+// engine and the same shading code, in the order the separate kernels would have used, so every
+// path arrives at the same radiance.  (Closest-hit traversal for the visibility rays too: whether
+// anything lies in (tmin, tmax) does not depend on the order in which the candidates are found.)
+// One sample per slot only (RenderParams::single).
+template <bool COUNT>
+struct TailJob {
+  static constexpr int kDebugRow = 0;  // row of the diagnostic build's counters
+  const RenderParams& p;
+  const SceneTables* sc;  // LDS copy of all the small tables
+  const uint32_t* lens;
+  uint32_t grab, parity;
+  const float4* entries;  // of the open block
+  uint32_t slot, state;   // state of the continuation ray in flight (bounce << 1 | after a specular lobe)
+  int stage;              // the ray in flight: 0 continuation, 1 light sample, 2 environment escape ray
+  uint32_t pending;       // kHasLightRay | kHasMisRay still to trace, kClamp to apply after them, kSurvive
+  static constexpr uint32_t kSurvive = 8u;
+  V3 beta;
+  float4 l4;              // the path's radiance so far
+  V3 light_c, sh_o, sh_d, next_o, next_d;
+  float far;
+  int own, light_quad;
+  uint32_t next_state;
+  uint32_t n_bounces, n_light, n_mis, n_cont;       // of the job in flight
+  uint32_t out_bounces, out_light, out_mis, out_cont;  // of the retired job, until the flush
+
+  RRT_DEV uint32_t open_block(uint32_t j) {
+    uint32_t n;
+    entries = ray_queue_block(p, p.a.rays_cont[parity], lens, j, grab, &n);
+    return n;
+  }
+  RRT_DEV bool begin(uint32_t i, Ray* ray) {
+    const float4 o = entries[2 * i], d = entries[2 * i + 1];
+    slot = __float_as_uint(o.w);
+    state = __float_as_uint(d.w);
+    beta = mk(p.a.trace[slot].beta);  // continuation rays have bounce >= 1
+    l4 = p.a.radiance[slot];
+    stage = 0;
+    pending = 0;
+    n_bounces = n_light = n_mis = 0;
+    n_cont = 1;
+    ray->o = mk(o);
+    ray->d = mk(d);
+    ray->tmin = 0.0f;
+    ray->tmax = kTriTMax;
+    ray->skip = -1;
+    return true;
+  }
+  // The next ray of this path, in the order connect and extend would trace them; false: the path is complete.
+  RRT_DEV bool next_ray(Ray* ray) {
+    if (pending & kHasLightRay) {
+      pending &= ~kHasLightRay;
+      if (own >= sc->n_tris + sc->n_rects + sc->n_planes) own = -1;  // spheres keep their t > 1e-4 guard
+      ray->o = sh_o;
+      ray->d = sh_d;
+      ray->tmin = 0.0f;
+      ray->tmax = fminf(far, kTriTMax);
+      ray->skip = own < sc->n_tris ? own : -1;
+      stage = 1;
+      ++n_light;
+      return true;
+    }
+    if (pending & kHasMisRay) {
+      pending &= ~kHasMisRay;
+      const float4 o = p.a.mis[slot].mis_o, d = p.a.mis[slot].mis_d;  // parked there by this lane
+      own = light_quad = -1;
+      far = INFINITY;
+      ray->o = mk(o);
+      ray->d = mk(d);
+      ray->tmin = 0.0f;
+      ray->tmax = kTriTMax;
+      ray->skip = -1;
+      stage = 2;
+      ++n_mis;
+      return true;
+    }
+    if (pending & kClamp) {
+      pending &= ~kClamp;
+      l4.x = fminf(l4.x, p.clamp); l4.y = fminf(l4.y, p.clamp); l4.z = fminf(l4.z, p.clamp);
+    }
+    if (pending & kSurvive) {
+      pending = 0;
+      state = next_state;
+      ray->o = next_o;
+      ray->d = next_d;
+      ray->tmin = 0.0f;
+      ray->tmax = kTriTMax;
+      ray->skip = -1;
+      stage = 0;
+      ++n_cont;
+      return true;
+    }
+    p.a.radiance[slot] = l4;
+    return false;
+  }
+  RRT_DEV bool advance(bool found, const Hit& tri_hit, const RayPre& r, Ray* ray) {
+    const bool others = sc->n_rects + sc->n_planes + sc->n_spheres > 0;
+    if (stage != 0) {
+      bool occluded = found;
+      if (!occluded && others) {
+        Hit h;
+        occluded = intersect_others<true>(sc, r, far, own, light_quad, &h);
+      }
+      if (!occluded) {
+        float4 c = f4(light_c, 0.0f);
+        if (stage != 1) c = p.a.mis[slot].mis_c;
+        l4.x += c.x; l4.y += c.y; l4.z += c.z;
+      }
+      return next_ray(ray);
+    }
+    Hit h = tri_hit;
+    if (others) intersect_others<false>(sc, r, h.t, -1, -1, &h);
+    if (h.prim < 0) {
+      // the ray escaped: after a specular bounce it sees the lights' environment term (src/tracer.rs:44-63)
+      if (state & 1u) {
+        const V3 le = escape_radiance(sc, p.env, r.d);
+        l4.x += beta.x * le.x; l4.y += beta.y * le.y; l4.z += beta.z * le.z;
+      }
+      p.a.radiance[slot] = l4;
+      return false;
+    }
+    uint32_t x, y, k;
+    slot_pixel(p, slot, &x, &y, &k);
+    const Surface s = h.prim < sc->n_tris ? surface_triangle(p.tris, p.tri_shade, h.prim, h.u, h.v, r.d)
+                                          : surface_other(sc, h.prim, h.t, r.o, r.d);
+    const ShadeOut o = shade_bounce(p, sc, s, h.prim, y * p.width + x, p.sample_begin + k, state >> 1, beta);
+    ++n_bounces;
+    pending = o.flags & (kHasLightRay | kHasMisRay);
+    if (pending && (o.flags & kClamp)) pending |= kClamp;  // as connect: only an entry with visibility work is clamped
+    if (o.flags & kHasLightRay) {
+      light_c = o.light_c;
+      sh_o = o.sh_o;
+      sh_d = o.sh_d;
+      far = o.sh_tmax;
+      light_quad = o.sh_skip;
+      own = h.prim;
+    }
+    if (o.flags & kHasMisRay) {
+      p.a.mis[slot].mis_o = f4(o.mis_o, 0.0f);
+      p.a.mis[slot].mis_d = f4(o.mis_d, 0.0f);
+      p.a.mis[slot].mis_c = f4(o.mis_c, 0.0f);
+    }
+    if (o.survive) {
+      pending |= kSurvive;
+      next_o = o.next_o;
+      next_d = o.next_d;
+      next_state = o.next_state;
+      beta = o.beta;
+    }
+    return next_ray(ray);
+  }
+  RRT_DEV void retire() {
+    out_bounces = n_bounces;
+    out_light = n_light;
+    out_mis = n_mis;
+    out_cont = n_cont;
+  }
+  // The pass's running totals: one atomic per counter and flush.
+  RRT_DEV void flush(bool done, uint32_t block) {
+    uint32_t b = done ? out_bounces : 0u, l = done ? out_light : 0u, m = done ? out_mis : 0u, c = done ? out_cont : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      b += (uint32_t)__shfl_xor((int)b, d);
+      l += (uint32_t)__shfl_xor((int)l, d);
+      m += (uint32_t)__shfl_xor((int)m, d);
+      c += (uint32_t)__shfl_xor((int)c, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      const uint32_t seg = block % kSegments;
+      if (b) atomicAdd(counter_at(p.a.counters, kRowBounces, seg), b);
+      if (l) atomicAdd(counter_at(p.a.counters, kRowLightRays, seg), l);
+      if (m) atomicAdd(counter_at(p.a.counters, kRowMisRays, seg), m);
+      if (c) atomicAdd(counter_at(p.a.counters, kRowContRays, seg), c);
+    }
+  }
+};
+
+#ifdef RRT_TAIL_WAVES
+#define RRT_TAIL_BOUNDS __launch_bounds__(rrt::kTraceBlock, RRT_TAIL_WAVES)
+#else
+#define RRT_TAIL_BOUNDS __launch_bounds__(rrt::kTraceBlock)
+#endif
+template <bool COUNT>
+__global__ void RRT_TAIL_BOUNDS k_tail(RenderParams p, uint32_t parity) {
+  RRT_DECLARE_TRACE_STACK();
+  __shared__ uint32_t table_words[(sizeof(SceneTables) + 3) / 4];
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.scene);
+    for (uint32_t i = threadIdx.x; i < (sizeof(SceneTables) + 3) / 4; i += blockDim.x) table_words[i] = src[i];
+  }
+  const SceneTables* sc = reinterpret_cast<const SceneTables*>(table_words);  // (queue_lengths below synchronises)
+  __shared__ uint32_t lens[kSegments + 1];
+  const uint32_t longest = queue_lengths(p, row_cont(parity), lens);
+  // small blocks: the jobs are long and few, and every wave should get some
+  const uint32_t grab = 64;
+  TraceCounters ctr = {0, 0};
+  TailJob<COUNT> job = {p, sc, lens, grab, parity};
+  trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
+                             queue_blocks(longest, grab), RRT_TAIL_QUORUM, job, &ctr, rrt_trace_stack);
+  flush_counters<COUNT>(p.stats, 1, ctr);
 }
 
 // ---------------------------------------------------------------- film

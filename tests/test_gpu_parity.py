@@ -812,3 +812,38 @@ def test_4k_sample_ranges_compose(rrt, buddha, gpu_ctx, parity_record):
     print("4K: max difference %.3g of the film's maximum" % diff)
     parity_record("compose_4k_1024spp", max_diff_over_film_max=diff)
     assert diff <= 1e-5
+
+
+@pytest.mark.parametrize("which", ["buddha", "mixed"])
+def test_tail_kernel_changes_nothing(rrt, buddha, mixed, gpu_ctx, which):
+    """RRT_OPT_TAIL_PATHS: the kernel that runs the last live paths to their end (continuation ray, shading,
+    visibility rays, next bounce, all by one lane) uses the traversal engine and the shading code of the
+    separate kernels in the same order: the film is the same bit for bit whether it never runs (0), takes over
+    late (the default) or right after the second iteration (2^30), and so are the ray and bounce counts."""
+    scene, rs = buddha if which == "buddha" else mixed[:2]
+    w, h, spp = (480, 270, 16) if which == "buddha" else (240, 180, 8)
+    cam = rrt.Camera.from_settings(rs, w, h)
+    s = rrt.make_settings(w, h, rs.depth_limit, rs.clamp, seed=13)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    films, stats = [], []
+    try:
+        for tail in (0, 1 << 30, 4096, 1 << 21):
+            gpu_ctx.set_option(rrt.OPT_TAIL_PATHS, tail)
+            gpu_ctx.set_option(rrt.OPT_TIMING, 1)  # launches are counted from the timing events
+            gpu_ctx.film_clear()
+            gpu_ctx.reset_stats()
+            gpu_ctx.render(s, 0, spp)
+            films.append(gpu_ctx.film_download())
+            st = gpu_ctx.stats()
+            stats.append((st.paths, st.rays_extend, st.rays_shadow, st.path_bounces))
+            # (with a small threshold the queues may run empty between two looks at their lengths: then it never starts)
+            assert st.launches_tail == (0 if tail == 0 else 1) or (tail == 4096 and st.launches_tail == 0), (tail, st.launches_tail)
+    finally:
+        gpu_ctx.set_option(rrt.OPT_TAIL_PATHS, 1 << 21)
+        gpu_ctx.set_option(rrt.OPT_TIMING, 0)
+    assert films[0][..., :3].max() > 0 and stats[0][3] > stats[0][0] // 8
+    for f, st in zip(films[1:], stats[1:]):
+        np.testing.assert_array_equal(f, films[0])
+        assert st == stats[0]
