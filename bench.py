@@ -177,6 +177,8 @@ def main():
         workload = ("scene/buddha %dx%d, %d spp %s, depth %d, clamp %g, aperture %g, microfacet plastic, "
                     "3 area + distant + environment lights with MIS" % (W, H, SPP, spp_label, depth_limit, clamp, rs.aperture))
     ctx = rr.Context(local_rank)
+    if os.environ.get("RRT_DEVICE_BVH_OVERRIDE"):  # diagnostic: 0 host build, 1 device build (default: by triangle count)
+        ctx.set_option(rr.OPT_DEVICE_BVH, int(os.environ["RRT_DEVICE_BVH_OVERRIDE"]))
     t_up = time.perf_counter()
     ctx.upload_scene(scene)
     upload_s = time.perf_counter() - t_up

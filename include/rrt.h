@@ -251,6 +251,13 @@ int rrt_occluded(rrt_ctx* ctx, const float* org_dir_tmax, uint32_t n, uint8_t* h
  * Has no counterpart in the reference (its hierarchy is the bvh crate's): a self-check. */
 int64_t rrt_bvh_selfcheck(const float* tri_pos, uint32_t n_tris, uint32_t* n_nodes, uint32_t* max_depth);
 
+/* The same check on the hierarchy the context holds on the device (downloaded for the purpose), whichever
+ * way it was built: tri_pos / n_tris must be the triangles of the uploaded scene.  Also checks that every
+ * leaf-ordered triangle record holds the triangle it names.  Optionally reports the node count, the depth,
+ * whether kernels built it (RRT_OPT_DEVICE_BVH) and how long they took.  Returns the number of violations. */
+int64_t rrt_bvh_check_uploaded(rrt_ctx* ctx, const float* tri_pos, uint32_t n_tris, uint32_t* n_nodes, uint32_t* max_depth,
+                               int* built_on_device, double* build_seconds);
+
 /* First-hit buffers for a denoiser (the reference's SampleResult carries normal and albedo
  * but leaves them zero, src/tracer.rs:36-37,65-68; its denoiser reads them from the film,
  * src/denoise.rs:9-23).  With RRT_OPT_AOVS on, rrt_render also adds, per pixel, the shading
@@ -272,6 +279,10 @@ enum {
                                   free device memory) */
   RRT_OPT_COUNT_TRAVERSAL = 4, /* 1: count nodes_visited / tris_tested (slower kernels; for calibration runs) */
   RRT_OPT_AOVS = 6,            /* 1: accumulate first-hit normal and albedo (rrt_aov_download); default 0 */
+  RRT_OPT_DEVICE_BVH = 8,      /* how rrt_upload_scene builds the hierarchy: 0 on the host (binned SAH, threads), 1 by kernels on
+                                  the device (Morton order + locally-ordered clustering; the triangles go up unsorted and the
+                                  leaf-ordered records are written there too), 2 (default) by kernels from 4 Mi triangles on,
+                                  where the host build would take seconds.  Replaces Bvh::build (src/scene.rs:196) either way. */
   RRT_OPT_TAIL_PATHS = 7,      /* once at most this many paths are still alive, one kernel runs each of them to its end
                                   (continuation ray, shading, visibility rays, next bounce ...) instead of further rounds of
                                   the separate kernels, each of which would wait for its longest ray; same film.  0: never.

@@ -41,6 +41,7 @@ pub const RRT_OPT_COUNT_TRAVERSAL: c_int = 4;
 pub const RRT_OPT_SIDE_STREAM: c_int = 5;
 pub const RRT_OPT_AOVS: c_int = 6;
 pub const RRT_OPT_TAIL_PATHS: c_int = 7;
+pub const RRT_OPT_DEVICE_BVH: c_int = 8;
 
 pub const RRT_NOALLOC_MAX_RAYS: u32 = 65536;
 
@@ -193,6 +194,15 @@ extern "C" {
     pub fn rrt_intersect_noalloc(ctx: *mut RrtCtx, org_dir: *const f32, n: u32, prim_id: *mut i32, t: *mut f32) -> c_int;
     pub fn rrt_occluded(ctx: *mut RrtCtx, org_dir_tmax: *const f32, n: u32, hit: *mut u8) -> c_int;
     pub fn rrt_bvh_selfcheck(tri_pos: *const f32, n_tris: u32, n_nodes: *mut u32, max_depth: *mut u32) -> i64;
+    pub fn rrt_bvh_check_uploaded(
+        ctx: *mut RrtCtx,
+        tri_pos: *const f32,
+        n_tris: u32,
+        n_nodes: *mut u32,
+        max_depth: *mut u32,
+        built_on_device: *mut c_int,
+        build_seconds: *mut f64,
+    ) -> i64;
     pub fn rrt_aov_download(ctx: *mut RrtCtx, host_normal_sum: *mut f32, host_albedo_sum: *mut f32) -> c_int;
     pub fn rrt_aov_device_ptr(ctx: *mut RrtCtx) -> *mut c_void;
     pub fn rrt_set_option(ctx: *mut RrtCtx, option: c_int, value: i64) -> c_int;

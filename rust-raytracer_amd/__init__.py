@@ -92,7 +92,7 @@ class RenderSettingsFile(C.Structure):
 MAT_MATTE, MAT_PLASTIC, MAT_MIRROR, MAT_GLASS = 0, 1, 2, 3
 LIGHT_POINT, LIGHT_AREA, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2, 3
 RECT_AABB_STRICT, RECT_AABB_INCLUSIVE, RECT_AABB_OFF = 0, 1, 2
-OPT_TIMING, OPT_BATCH_SAMPLES, OPT_MAX_SLOTS, OPT_COUNT_TRAVERSAL, OPT_SIDE_STREAM, OPT_AOVS, OPT_TAIL_PATHS = 1, 2, 3, 4, 5, 6, 7
+OPT_TIMING, OPT_BATCH_SAMPLES, OPT_MAX_SLOTS, OPT_COUNT_TRAVERSAL, OPT_SIDE_STREAM, OPT_AOVS, OPT_TAIL_PATHS, OPT_DEVICE_BVH = 1, 2, 3, 4, 5, 6, 7, 8
 FILTER_NONE, FILTER_GAUSSIAN, FILTER_MITCHELL = 0, 1, 2
 NOALLOC_MAX_RAYS = 65536  # RRT_NOALLOC_MAX_RAYS
 
@@ -102,7 +102,7 @@ RRT_SYMBOLS = ["rrt_device_count", "rrt_create", "rrt_destroy", "rrt_set_stream"
                "rrt_film_device_ptr", "rrt_render", "rrt_synchronize", "rrt_film_reduce", "rrt_intersect",
                "rrt_occluded", "rrt_set_option", "rrt_get_stats", "rrt_reset_stats", "rrt_last_error",
                "rrt_set_filter", "rrt_film_tonemap", "rrt_bvh_selfcheck", "rrt_aov_download", "rrt_aov_device_ptr",
-               "rrt_intersect_noalloc"]
+               "rrt_intersect_noalloc", "rrt_bvh_check_uploaded"]
 RRTH_SYMBOLS = ["rrth_last_error", "rrth_scene_load", "rrth_scene_load_with_mesh", "rrth_scene_free",
                 "rrth_scene_desc", "rrth_scene_set_rect_aabb_mode", "rrth_scene_set_material",
                 "rrth_load_render_settings", "rrth_camera_matrices", "rrth_camera_generate_ray", "rrth_tonemap",
@@ -152,6 +152,9 @@ def hip_lib():
         lib.rrt_last_error.restype = C.c_char_p
         lib.rrt_bvh_selfcheck.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         lib.rrt_bvh_selfcheck.restype = C.c_int64
+        lib.rrt_bvh_check_uploaded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                               C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        lib.rrt_bvh_check_uploaded.restype = C.c_int64
         _hip = lib
     return _hip
 
@@ -516,6 +519,16 @@ class Context:
         hit = np.empty(n, dtype=np.uint8)
         self._check(self._lib.rrt_occluded(self._h, rays.ctypes.data, n, hit.ctypes.data), "rrt_occluded")
         return hit
+
+    def bvh_check(self, tri_pos):
+        """rrt_bvh_check_uploaded: (violations, nodes, depth, built on the device?, device build seconds)."""
+        pos = np.ascontiguousarray(tri_pos, dtype=np.float32).reshape(-1, 9)
+        nodes, depth, dev, secs = C.c_uint32(), C.c_uint32(), C.c_int(), C.c_double()
+        bad = self._lib.rrt_bvh_check_uploaded(self._h, pos.ctypes.data, pos.shape[0], C.byref(nodes), C.byref(depth),
+                                               C.byref(dev), C.byref(secs))
+        if bad < 0:
+            self._check(int(bad), "rrt_bvh_check_uploaded")
+        return int(bad), nodes.value, depth.value, bool(dev.value), secs.value
 
     def set_option(self, option, value):
         self._check(self._lib.rrt_set_option(self._h, option, int(value)), "rrt_set_option")

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
 
-HIP_SOURCES = ["rrt_api.hip", "bvh_build.cpp"]
+HIP_SOURCES = ["rrt_api.hip", "bvh_build.cpp", "bvh_build_device.hip"]
 HIP_HEADERS = ["rrt_device.h", "rrt_threads.h", "rrt_math.h", "rrt_trace.h", "rrt_shade.h", "rrt_kernels.h"]
 HOST_SOURCES = ["yaml_lite.cpp", "obj_loader.cpp", "scene.cpp", "camera_film.cpp", "renderer.cpp", "capi.cpp"]
 HOST_HEADERS = ["yaml_lite.h", "obj_loader.h", "rrt_host.hpp"]

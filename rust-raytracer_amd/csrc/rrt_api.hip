@@ -41,6 +41,10 @@ constexpr uint32_t kQueueGridBlocks = 8192;  // 32 blocks per CU for the kernels
 #ifndef RRT_OVERLAP_FROM
 #define RRT_OVERLAP_FROM 1   // first iteration whose visibility rays run beside the next extend (-1: never)
 #endif
+#ifndef RRT_AUTO_DEVICE_BUILD_TRIS
+#define RRT_AUTO_DEVICE_BUILD_TRIS (4u << 20)
+#endif
+constexpr uint32_t kAutoDeviceBuildTris = RRT_AUTO_DEVICE_BUILD_TRIS;  // from here on the hierarchy is built by kernels unless told otherwise
 #ifndef RRT_TAIL_PATHS
 #define RRT_TAIL_PATHS (1u << 21)
 #endif
@@ -113,6 +117,10 @@ struct rrt_ctx {
   SceneTables h_scene;
   uint32_t n_nodes = 0;
   uint64_t bvh_bytes = 0;
+  uint32_t n_tris = 0, bvh_max_depth = 0;
+  bool bvh_built_on_device = false;
+  double bvh_build_seconds = 0.0;   // device build only
+  int device_bvh = 2;               // RRT_OPT_DEVICE_BVH: 0 host build, 1 device build, 2 by triangle count
 
   // camera
   bool have_camera = false;
@@ -659,25 +667,27 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   free_scene(ctx);
 
-  // ---- BVH over the triangles, then the leaf-ordered records
+  // ---- BVH over the triangles, then the leaf-ordered records: on the host here, or by kernels further down
+  const bool device_build = sd->n_tris >= kDeviceBuildMinTris &&
+                            (ctx->device_bvh == 1 || (ctx->device_bvh == 2 && sd->n_tris >= kAutoDeviceBuildTris));
   BvhBuildResult bvh;
   struct BvhOwner {  // frees the hierarchy on every way out (free_bvh leaves it empty, so the explicit calls below are harmless)
     BvhBuildResult* b;
     ~BvhOwner() { free_bvh(b); }
   } bvh_owner{&bvh};
-  if (!build_bvh(sd->tri_pos, sd->n_tris, 0, &bvh)) return fail(ctx, RRT_E_NOMEM, "BVH build: out of host memory");
+  if (!device_build && !build_bvh(sd->tri_pos, sd->n_tris, 0, &bvh)) return fail(ctx, RRT_E_NOMEM, "BVH build: out of host memory");
   // (malloc'ed, not vectors: 100 bytes per triangle that need no zeroing first)
-  TriIsect* tris = (TriIsect*)std::malloc(sizeof(TriIsect) * std::max<size_t>(sd->n_tris, 1));
-  TriShade* shade = (TriShade*)std::malloc(sizeof(TriShade) * std::max<size_t>(sd->n_tris, 1));
+  TriIsect* tris = device_build ? nullptr : (TriIsect*)std::malloc(sizeof(TriIsect) * std::max<size_t>(sd->n_tris, 1));
+  TriShade* shade = device_build ? nullptr : (TriShade*)std::malloc(sizeof(TriShade) * std::max<size_t>(sd->n_tris, 1));
   struct HostRecords {
     TriIsect* a; TriShade* b;
     ~HostRecords() { std::free(a); std::free(b); }
   } host_records{tris, shade};
-  if (!tris || !shade) {
+  if (!device_build && (!tris || !shade)) {
     free_bvh(&bvh);
     return fail(ctx, RRT_E_NOMEM, "triangle records: out of host memory");
   }
-  parallel_for(sd->n_tris, [&](uint32_t slot) {
+  if (!device_build) parallel_for(sd->n_tris, [&](uint32_t slot) {
     const uint32_t id = bvh.order[slot];
     const float* p = sd->tri_pos + (size_t)id * 9;
     const float* n = sd->tri_nrm + (size_t)id * 9;
@@ -784,30 +794,58 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   std::vector<DeviceMaterial> mats(sd->n_materials);
   for (uint32_t i = 0; i < sd->n_materials; ++i) mats[i] = digest_material(sd->materials[i]);
 
+  uint32_t max_depth = bvh.max_depth;
+  ctx->n_nodes = bvh.n_nodes;
+  ctx->bvh_built_on_device = device_build;
+  ctx->bvh_build_seconds = 0.0;
+  if (device_build) {
+    DeviceBvhResult built;
+    std::string why;
+    rc = build_bvh_device(sd->tri_pos, sd->tri_nrm, sd->tri_mat, sd->n_tris, ctx->stream, &built, &why);
+    ctx->d_nodes = built.d_nodes;  // (free_scene releases them on the error paths below)
+    ctx->d_tris = built.d_tris;
+    ctx->d_tri_shade = built.d_tri_shade;
+    if (rc != RRT_OK) {
+      free_scene(ctx);
+      return fail(ctx, rc, why);
+    }
+    max_depth = built.max_depth;
+    ctx->n_nodes = built.n_nodes;
+    ctx->bvh_build_seconds = built.seconds;
+    if (std::getenv("RRT_BVH_TIMING"))
+      std::fprintf(stderr, "bvh build on the device: %u triangles, %u clustering rounds, %u 4-wide nodes, depth %u, %.3f s\n", sd->n_tris,
+                   built.rounds, built.n_nodes, built.max_depth, built.seconds);
+  }
   // every 4-wide node on a ray's way down leaves at most 3 entries on the traversal stack
-  if (3ull * bvh.max_depth + 1 > (uint64_t)kStackDepth) {
+  if (3ull * max_depth + 1 > (uint64_t)kStackDepth) {
     free_bvh(&bvh);
+    free_scene(ctx);
     return fail(ctx, RRT_E_UNSUPPORTED, "hierarchy too deep for the traversal stack");
   }
+  ctx->bvh_max_depth = max_depth;
 
   // ---- upload
-  ctx->n_nodes = bvh.n_nodes;
-  rc = dev_alloc(ctx, &ctx->d_nodes, bvh.n_nodes);
-  if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_tris, sd->n_tris);
-  if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_tri_shade, sd->n_tris);
+  rc = RRT_OK;
+  if (!device_build) {
+    rc = dev_alloc(ctx, &ctx->d_nodes, bvh.n_nodes);
+    if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_tris, sd->n_tris);
+    if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_tri_shade, sd->n_tris);
+  }
   if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_materials, sd->n_materials);
   if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_scene, 1);
   if (rc == RRT_OK && st.has_env) rc = dev_alloc(ctx, &ctx->d_env, (size_t)sd->env_w * sd->env_h * 3);
   if (rc != RRT_OK) { free_bvh(&bvh); free_scene(ctx); return rc; }
-  hipError_t e = hipMemcpy(ctx->d_nodes, bvh.nodes, sizeof(BvhNode) * (size_t)bvh.n_nodes, hipMemcpyHostToDevice);
-  if (e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tris, tris, sizeof(TriIsect) * (size_t)sd->n_tris, hipMemcpyHostToDevice);
-  if (e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tri_shade, shade, sizeof(TriShade) * (size_t)sd->n_tris, hipMemcpyHostToDevice);
+  hipError_t e = hipSuccess;
+  if (!device_build) e = hipMemcpy(ctx->d_nodes, bvh.nodes, sizeof(BvhNode) * (size_t)bvh.n_nodes, hipMemcpyHostToDevice);
+  if (!device_build && e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tris, tris, sizeof(TriIsect) * (size_t)sd->n_tris, hipMemcpyHostToDevice);
+  if (!device_build && e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tri_shade, shade, sizeof(TriShade) * (size_t)sd->n_tris, hipMemcpyHostToDevice);
   if (e == hipSuccess && sd->n_materials) e = hipMemcpy(ctx->d_materials, mats.data(), sizeof(DeviceMaterial) * mats.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(ctx->d_scene, &st, sizeof(st), hipMemcpyHostToDevice);
   if (e == hipSuccess && st.has_env) e = hipMemcpy(ctx->d_env, sd->env_rgb8, (size_t)sd->env_w * sd->env_h * 3, hipMemcpyHostToDevice);
   free_bvh(&bvh);
   if (e != hipSuccess) { free_scene(ctx); return fail(ctx, RRT_E_DEVICE, std::string("scene upload: ") + hipGetErrorString(e)); }
   ctx->bvh_bytes = sizeof(BvhNode) * (uint64_t)ctx->n_nodes + (sizeof(TriIsect) + sizeof(TriShade)) * (uint64_t)sd->n_tris;
+  ctx->n_tris = sd->n_tris;
   ctx->have_scene = true;
   return RRT_OK;
 }
@@ -1246,6 +1284,10 @@ int rrt_set_option(rrt_ctx* ctx, int option, int64_t value) {
     case RRT_OPT_COUNT_TRAVERSAL: ctx->count_traversal = value != 0; return RRT_OK;
     case RRT_OPT_SIDE_STREAM: ctx->side_stream_allowed = value != 0; return RRT_OK;
     case RRT_OPT_AOVS: ctx->aovs = value != 0; return RRT_OK;
+    case RRT_OPT_DEVICE_BVH:
+      if (value < 0 || value > 2) return fail(ctx, RRT_E_INVALID, "device BVH option out of range");
+      ctx->device_bvh = (int)value;
+      return RRT_OK;
     case RRT_OPT_TAIL_PATHS:
       if (value < 0 || value > (int64_t)kSlotLimit) return fail(ctx, RRT_E_INVALID, "tail paths out of range");
       ctx->tail_paths = (uint32_t)value;
@@ -1323,6 +1365,56 @@ int64_t rrt_bvh_selfcheck(const float* tri_pos, uint32_t n_tris, uint32_t* n_nod
   free_bvh(&bvh);
   if (!ok) return RRT_E_NOMEM;
   return (int64_t)std::min<uint64_t>(bad, (uint64_t)INT64_MAX);
+}
+
+int64_t rrt_bvh_check_uploaded(rrt_ctx* ctx, const float* tri_pos, uint32_t n_tris, uint32_t* n_nodes, uint32_t* max_depth,
+                               int* built_on_device, double* build_seconds) {
+  if (!ctx) return fail(nullptr, RRT_E_INVALID, "null context");
+  if (!ctx->have_scene) return fail(ctx, RRT_E_STATE, "no scene uploaded");
+  if ((!tri_pos && n_tris) || n_tris != ctx->n_tris) return fail(ctx, RRT_E_INVALID, "triangle array does not match the uploaded scene");
+  int rc = bind_device(ctx);
+  if (rc != RRT_OK) return rc;
+  if (n_nodes) *n_nodes = ctx->n_nodes;
+  if (max_depth) *max_depth = ctx->bvh_max_depth;
+  if (built_on_device) *built_on_device = ctx->bvh_built_on_device ? 1 : 0;
+  if (build_seconds) *build_seconds = ctx->bvh_build_seconds;
+  BvhBuildResult b;
+  b.n_nodes = ctx->n_nodes;
+  b.max_depth = ctx->bvh_max_depth;
+  b.nodes = (BvhNode*)std::malloc(sizeof(BvhNode) * std::max<size_t>(ctx->n_nodes, 1));
+  b.order = (uint32_t*)std::malloc(sizeof(uint32_t) * std::max<size_t>(n_tris, 1));
+  TriIsect* recs = (TriIsect*)std::malloc(sizeof(TriIsect) * std::max<size_t>(n_tris, 1));
+  int64_t result = RRT_E_NOMEM;
+  if (b.nodes && b.order && recs) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(b.nodes, ctx->d_nodes, sizeof(BvhNode) * (size_t)ctx->n_nodes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n_tris) e = hipMemcpy(recs, ctx->d_tris, sizeof(TriIsect) * (size_t)n_tris, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      result = fail(ctx, RRT_E_DEVICE, std::string("rrt_bvh_check_uploaded: ") + hipGetErrorString(e));
+    } else {
+      uint64_t bad = 0;
+      for (uint32_t i = 0; i < n_tris; ++i) {
+        uint32_t id;
+        std::memcpy(&id, &recs[i].v0.w, 4);
+        if (id >= n_tris) { ++bad; id = 0; }
+        b.order[i] = id;
+        // the record must hold the triangle it names
+        const float* p = tri_pos + (size_t)id * 9;
+        if (recs[i].v0.x != p[0] || recs[i].v0.y != p[1] || recs[i].v0.z != p[2] || recs[i].e1.x != p[3] - p[0] ||
+            recs[i].e2.z != p[8] - p[2])
+          ++bad;
+      }
+      try {
+        bad += validate_bvh(tri_pos, n_tris, b);
+        result = (int64_t)std::min<uint64_t>(bad, (uint64_t)INT64_MAX);
+      } catch (...) {
+        result = RRT_E_NOMEM;
+      }
+    }
+  }
+  std::free(recs);
+  free_bvh(&b);
+  return result;
 }
 
 int rrt_reset_stats(rrt_ctx* ctx) {

@@ -5,6 +5,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <string>
+
 #include "../../include/rrt.h"
 
 #if defined(__HIPCC__)
@@ -146,5 +148,23 @@ bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuild
 void free_bvh(BvhBuildResult* r);
 // Number of violations of the hierarchy's invariants (0 = sound): see bvh_build.cpp.
 uint64_t validate_bvh(const float* tri_pos, uint32_t n_tris, const BvhBuildResult& b);
+
+#if defined(__HIPCC__)
+// Device BVH builder (bvh_build_device.hip): the hierarchy and the leaf-ordered triangle records,
+// built by kernels and left in device memory (hipMalloc'ed; the caller owns them, also after an error).
+constexpr uint32_t kDeviceBuildMinTris = 64;
+struct DeviceBvhResult {
+  BvhNode* d_nodes = nullptr;
+  TriIsect* d_tris = nullptr;
+  TriShade* d_tri_shade = nullptr;
+  uint32_t n_nodes = 0;
+  uint32_t max_depth = 0;   // inner nodes on the longest root-to-leaf chain
+  uint32_t rounds = 0;      // clustering rounds it took
+  double seconds = 0.0;     // wall clock, upload of the triangles included
+};
+// tri_pos / tri_nrm: host [n][3][3] floats, tri_mat: host [n].  Returns an RRT_* code; *error says what failed.
+int build_bvh_device(const float* tri_pos, const float* tri_nrm, const uint32_t* tri_mat, uint32_t n, hipStream_t stream,
+                     DeviceBvhResult* out, std::string* error);
+#endif
 
 }  // namespace rrt

@@ -847,3 +847,79 @@ def test_tail_kernel_changes_nothing(rrt, buddha, mixed, gpu_ctx, which):
     for f, st in zip(films[1:], stats[1:]):
         np.testing.assert_array_equal(f, films[0])
         assert st == stats[0]
+
+
+def _traversal_cost(rrt, ctx, cam, s, spp):
+    """Mean nodes and triangles fetched per ray over a small render (counting build of the kernels)."""
+    ctx.set_camera(cam)
+    ctx.film_alloc(s.width, s.height)
+    ctx.set_option(rrt.OPT_COUNT_TRAVERSAL, 1)
+    try:
+        ctx.reset_stats()
+        ctx.render(s, 0, spp)
+        st = ctx.stats()
+    finally:
+        ctx.set_option(rrt.OPT_COUNT_TRAVERSAL, 0)
+    rays = st.rays_extend + st.rays_shadow
+    return st.nodes_visited / rays, st.tris_tested / rays, ctx.film_download()
+
+
+@pytest.mark.parametrize("which", ["cornell", "buddha68k", "stress24"])
+def test_device_built_hierarchy(rrt, cornell, buddha, gpu_ctx, parity_record, which):
+    """RRT_OPT_DEVICE_BVH = 1: the hierarchy built by kernels (Morton order + locally-ordered clustering, 4-wide
+    collapse and quantisation on the device) against the host-built one (binned SAH): sound by the same invariant
+    check (every triangle inside every box on the way to it, each in exactly one leaf, records in leaf order), the
+    same first hits on a ray set, the same film up to the paths that meet an edge (a ray through a shared edge
+    takes whichever of the two triangles its traversal order reaches first), and a traversal cost -- nodes
+    fetched per ray over a render -- within 15 % of the host tree's."""
+    if which == "cornell":
+        scene, rs = cornell
+        w, h, spp, depth, clamp = 128, 128, 4, rs.depth_limit, rs.clamp
+        cam = rrt.Camera.from_settings(rs, w, h)
+    elif which == "buddha68k":
+        scene, rs = buddha
+        w, h, spp, depth, clamp = 240, 135, 4, rs.depth_limit, rs.clamp
+        cam = rrt.Camera.from_settings(rs, w, h)
+    else:
+        _, (scene, cam_args, depth, clamp) = scenes_util.stress_scene(rrt, 24, grid=(4, 3, 2))
+        w, h, spp = 160, 90, 4
+        cam = rrt.Camera(image_width=w, image_height=h, **cam_args)
+    d = scene.desc()
+    pos = np.ctypeslib.as_array(d.tri_pos, shape=(d.n_tris, 9)).copy()
+    s = rrt.make_settings(w, h, depth, clamp, seed=17)
+    rng = np.random.default_rng(4)
+    px = rng.uniform(0, [w, h], size=(4000, 2))
+    rays = np.array([np.concatenate(cam.generate_ray(x, y)) for x, y in px]).astype(np.float32)
+    results = {}
+    try:
+        for mode in (0, 1):
+            gpu_ctx.set_option(rrt.OPT_DEVICE_BVH, mode)
+            gpu_ctx.upload_scene(scene)
+            bad, nodes, tree_depth, on_device, secs = gpu_ctx.bvh_check(pos)
+            assert bad == 0 and on_device == bool(mode), (mode, bad, on_device)
+            prim, t = gpu_ctx.intersect(rays)
+            odt = np.concatenate([rays, np.full((len(rays), 1), 1.5, np.float32)], axis=1)
+            occ = gpu_ctx.occluded(odt)
+            nodes_per_ray, tris_per_ray, film = _traversal_cost(rrt, gpu_ctx, cam, s, spp)
+            results[mode] = dict(prim=prim, t=t, occ=occ, nodes=nodes, depth=tree_depth, secs=secs, npr=nodes_per_ray,
+                                 tpr=tris_per_ray, film=film.astype(np.float64))
+    finally:
+        gpu_ctx.set_option(rrt.OPT_DEVICE_BVH, 2)
+    host, dev = results[0], results[1]
+    same = host["prim"] == dev["prim"]
+    print("%s: %d triangles; host tree %d nodes depth %d, %.2f nodes + %.2f triangles per ray; device tree %d nodes depth %d, "
+          "%.2f + %.2f per ray, built in %.1f ms; first hits agree on %.5f, occlusion on %.5f" % (
+              which, d.n_tris, host["nodes"], host["depth"], host["npr"], host["tpr"], dev["nodes"], dev["depth"], dev["npr"],
+              dev["tpr"], dev["secs"] * 1e3, same.mean(), (host["occ"] == dev["occ"]).mean()))
+    assert same.mean() >= 0.999 and (host["prim"] >= 0).sum() > 500
+    np.testing.assert_array_equal(host["t"][same], dev["t"][same])
+    assert (host["occ"] == dev["occ"]).mean() >= 0.999
+    np.testing.assert_array_equal(host["film"][..., 3], dev["film"][..., 3])
+    rel = np.abs(host["film"][..., :3] - dev["film"][..., :3]).sum() / host["film"][..., :3].sum()
+    assert rel <= 2e-3, rel
+    cost_ratio = (dev["npr"] * 64 + dev["tpr"] * 36) / (host["npr"] * 64 + host["tpr"] * 36)
+    parity_record("device_bvh_%s" % which, triangles=int(d.n_tris), first_hit_agreement=same.mean(), film_rel_diff=rel,
+                  nodes_per_ray_host=host["npr"], nodes_per_ray_device=dev["npr"], tris_per_ray_host=host["tpr"],
+                  tris_per_ray_device=dev["tpr"], traversal_bytes_ratio=cost_ratio, device_build_ms=dev["secs"] * 1e3)
+    assert dev["npr"] <= 1.15 * host["npr"], (dev["npr"], host["npr"])
+    assert cost_ratio <= 1.15, cost_ratio
