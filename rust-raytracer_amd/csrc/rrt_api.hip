@@ -1134,6 +1134,8 @@ int render_impl(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint
   p.clamp = (float)s->clamp;
   p.filter_table = ctx->filter_method != RRT_FILTER_NONE ? ctx->d_filter_table : nullptr;
   p.filter_radius = ctx->filter_radius;
+  p.escape_lit = (ctx->h_scene.has_env || ctx->h_scene.distant_env[0] != 0.0f || ctx->h_scene.distant_env[1] != 0.0f ||
+                  ctx->h_scene.distant_env[2] != 0.0f) ? 1u : 0u;
   // rounds of one sample per slot (see above), or one round in which the slots take every k-th sample
   const bool rounds = !regenerating;
   for (uint64_t s0 = sample_begin; s0 < sample_end; s0 += rounds ? k : n_samples) {

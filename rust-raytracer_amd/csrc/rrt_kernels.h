@@ -176,6 +176,9 @@ struct RenderParams {
   // nothing is banked -- film reads `radiance` directly, a path that ends just stops, and the
   // start queue only sees rays that escaped after a specular bounce (they still owe the environment).
   uint32_t single;
+  // Something is to be had from a ray that leaves the scene (an environment map or a distant light,
+  // src/tracer.rs:44-63): otherwise, with one sample per slot, such a ray just ends its path.
+  uint32_t escape_lit;
 };
 
 RRT_DEV uint32_t* counter_at(uint32_t* counters, uint32_t row, uint32_t seg) {
@@ -469,7 +472,7 @@ struct ExtendJob {
     hit_surface = h.prim >= 0;
     // shade needs the whole ray, start (for a ray that escaped and still has something to collect) its
     // direction and state
-    if (hit_surface || !p.single || (state & 1u)) p.a.trace[slot].ray_d = f4(r.d, __uint_as_float(state));
+    if (hit_surface || !p.single || ((state & 1u) && p.escape_lit)) p.a.trace[slot].ray_d = f4(r.d, __uint_as_float(state));
     if (hit_surface) {
       if (h.prim >= sc->n_tris) p.a.trace[slot].ray_o = f4(r.o, 0.0f);  // only the analytic shapes' shading reads it
       p.a.trace[slot].hit = make_float4(__int_as_float(h.prim), h.t, h.u, h.v);
@@ -479,7 +482,7 @@ struct ExtendJob {
   RRT_DEV void retire() {
     out_slot = slot;
     out_hit = hit_surface;
-    out_owes = !p.single || (state & 1u);
+    out_owes = !p.single || ((state & 1u) && p.escape_lit);
   }
   // Two queues, two atomics: both issued before either result is used.
   RRT_DEV void flush(bool done, uint32_t block) {
