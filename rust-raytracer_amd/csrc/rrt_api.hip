@@ -789,6 +789,28 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
     }
   }
   st.has_env = st.infinite_light >= 0 ? 1 : 0;
+  {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < sd->n_rects; ++i)
+      for (int corner = 0; corner < 4; ++corner)
+        for (int k = 0; k < 3; ++k) {
+          const double v = sd->rects[i].pos[k] + ((corner & 1) ? sd->rects[i].side_a[k] : 0.0) + ((corner & 2) ? sd->rects[i].side_b[k] : 0.0);
+          lo[k] = std::min(lo[k], v);
+          hi[k] = std::max(hi[k], v);
+        }
+    for (uint32_t i = 0; i < sd->n_spheres; ++i)
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = std::min(lo[k], sd->spheres[i].center[k] - std::fabs(sd->spheres[i].radius));
+        hi[k] = std::max(hi[k], sd->spheres[i].center[k] + std::fabs(sd->spheres[i].radius));
+      }
+    for (int k = 0; k < 3; ++k) {
+      // padded by far more than f32 rounding of a hit point on the shapes
+      const double pad = 1e-3 * std::max(1.0, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+      const bool bounded = sd->n_planes == 0 && lo[k] <= hi[k];
+      st.others_bmin[k] = sd->n_planes ? -INFINITY : (bounded ? (float)(lo[k] - pad) : INFINITY);
+      st.others_bmax[k] = sd->n_planes ? INFINITY : (bounded ? (float)(hi[k] + pad) : -INFINITY);
+    }
+  }
   st.env_w = (int)sd->env_w;
   st.env_h = (int)sd->env_h;
   std::vector<DeviceMaterial> mats(sd->n_materials);
@@ -833,7 +855,7 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   }
   if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_materials, sd->n_materials);
   if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_scene, 1);
-  if (rc == RRT_OK && st.has_env) rc = dev_alloc(ctx, &ctx->d_env, (size_t)sd->env_w * sd->env_h * 3);
+  if (rc == RRT_OK && st.has_env) rc = dev_alloc(ctx, &ctx->d_env, (size_t)sd->env_w * sd->env_h * 4);
   if (rc != RRT_OK) { free_bvh(&bvh); free_scene(ctx); return rc; }
   hipError_t e = hipSuccess;
   if (!device_build) e = hipMemcpy(ctx->d_nodes, bvh.nodes, sizeof(BvhNode) * (size_t)bvh.n_nodes, hipMemcpyHostToDevice);
@@ -841,7 +863,17 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   if (!device_build && e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tri_shade, shade, sizeof(TriShade) * (size_t)sd->n_tris, hipMemcpyHostToDevice);
   if (e == hipSuccess && sd->n_materials) e = hipMemcpy(ctx->d_materials, mats.data(), sizeof(DeviceMaterial) * mats.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(ctx->d_scene, &st, sizeof(st), hipMemcpyHostToDevice);
-  if (e == hipSuccess && st.has_env) e = hipMemcpy(ctx->d_env, sd->env_rgb8, (size_t)sd->env_w * sd->env_h * 3, hipMemcpyHostToDevice);
+  if (e == hipSuccess && st.has_env) {
+    // one 4-byte texel per lookup instead of three byte loads
+    std::vector<uint8_t> rgba((size_t)sd->env_w * sd->env_h * 4);
+    for (size_t i = 0; i < (size_t)sd->env_w * sd->env_h; ++i) {
+      rgba[4 * i + 0] = sd->env_rgb8[3 * i + 0];
+      rgba[4 * i + 1] = sd->env_rgb8[3 * i + 1];
+      rgba[4 * i + 2] = sd->env_rgb8[3 * i + 2];
+      rgba[4 * i + 3] = 0;
+    }
+    e = hipMemcpy(ctx->d_env, rgba.data(), rgba.size(), hipMemcpyHostToDevice);
+  }
   free_bvh(&bvh);
   if (e != hipSuccess) { free_scene(ctx); return fail(ctx, RRT_E_DEVICE, std::string("scene upload: ") + hipGetErrorString(e)); }
   ctx->bvh_bytes = sizeof(BvhNode) * (uint64_t)ctx->n_nodes + (sizeof(TriIsect) + sizeof(TriShade)) * (uint64_t)sd->n_tris;
@@ -869,6 +901,9 @@ int rrt_set_camera(rrt_ctx* ctx, const double raster_to_camera[16], const double
   std::memcpy(ctx->camera.camera_to_world, camera_to_world, sizeof(double) * 16);
   ctx->camera.aperture = aperture;
   ctx->camera.focal_distance = focal_distance;
+  for (int i = 0; i < 12; ++i) ctx->camera.camera_to_world_f[i] = (float)camera_to_world[i];
+  ctx->camera.aperture_f = (float)aperture;
+  ctx->camera.focal_distance_f = (float)focal_distance;
   {
     const double* m = ctx->camera.raster_to_camera;
     ctx->camera.const_inv_w = (m[12] == 0.0 && m[13] == 0.0 && m[15] != 0.0) ? 1.0 / m[15] : 0.0;

@@ -123,6 +123,9 @@ struct SceneTables {
   int env_w, env_h;
   float distant_env[3];  // sum of DistantLight intensities: what every escaping ray picks up (lights/distant.rs:62-64)
   int infinite_light;    // index of the InfiniteArea light or -1
+  // Box around every quad and sphere (their true extent, slightly padded; infinite when the scene has a plane): a ray
+  // whose segment of interest misses it needs none of the per-shape tests.
+  float others_bmin[3], others_bmax[3];
   DeviceRect rects[RRT_MAX_RECTS];
   DevicePlane planes[RRT_MAX_PLANES];
   DeviceSphere spheres[RRT_MAX_SPHERES];
@@ -134,6 +137,9 @@ struct CameraParams {
   double camera_to_world[16];
   double aperture, focal_distance;
   double const_inv_w;  // 1 / w of raster_to_camera * (x, y, 0, 1) when that w does not depend on x and y (any perspective or orthographic projection), else 0
+  // the f32 values the ray set-up works with, rounded once on the host instead of once per ray
+  float camera_to_world_f[12];
+  float aperture_f, focal_distance_f;
 };
 
 // Host BVH builder (bvh_build.cpp).  Produces nodes and the leaf order.

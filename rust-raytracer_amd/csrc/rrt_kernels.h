@@ -305,19 +305,19 @@ RRT_DEV void camera_ray(const CameraParams& cam, uint32_t x, uint32_t y, const R
   if (cam.aperture > 0.0) {
     float lx, ly;
     concentric_sample_disk(r.u[2], r.u[3], &lx, &ly);
-    lx *= (float)cam.aperture;
-    ly *= (float)cam.aperture;
-    const float ft = (float)cam.focal_distance / d.z;
+    lx *= cam.aperture_f;
+    ly *= cam.aperture_f;
+    const float ft = cam.focal_distance_f / d.z;
     o = mk(lx, ly, 0.0f);
     d = normalize(d * ft - o);
   }
-  const double* w = cam.camera_to_world;
-  *org = mk((float)w[0] * o.x + (float)w[1] * o.y + (float)w[2] * o.z + (float)w[3],
-            (float)w[4] * o.x + (float)w[5] * o.y + (float)w[6] * o.z + (float)w[7],
-            (float)w[8] * o.x + (float)w[9] * o.y + (float)w[10] * o.z + (float)w[11]);
-  *dir = normalize(mk((float)w[0] * d.x + (float)w[1] * d.y + (float)w[2] * d.z,
-                      (float)w[4] * d.x + (float)w[5] * d.y + (float)w[6] * d.z,
-                      (float)w[8] * d.x + (float)w[9] * d.y + (float)w[10] * d.z));
+  const float* w = cam.camera_to_world_f;  // rows of the 3 x 4 part
+  *org = mk(w[0] * o.x + w[1] * o.y + w[2] * o.z + w[3],
+            w[4] * o.x + w[5] * o.y + w[6] * o.z + w[7],
+            w[8] * o.x + w[9] * o.y + w[10] * o.z + w[11]);
+  *dir = normalize(mk(w[0] * d.x + w[1] * d.y + w[2] * d.z,
+                      w[4] * d.x + w[5] * d.y + w[6] * d.z,
+                      w[8] * d.x + w[9] * d.y + w[10] * d.z));
 }
 
 RRT_DEV const float4* ray_queue_block(const RenderParams& p, const float4* __restrict__ queue, const uint32_t* lens, uint32_t j,

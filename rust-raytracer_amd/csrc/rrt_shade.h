@@ -411,8 +411,10 @@ RRT_DEV V3 env_lookup(const SceneTables* __restrict__ sc, const uint8_t* __restr
   const float v = clampf(py, 0.0f, 1.0f);
   const int x = min((int)(u * (float)sc->env_w), sc->env_w - 1);
   const int y = min((int)(v * (float)sc->env_h), sc->env_h - 1);
-  const uint8_t* t = env + ((size_t)y * sc->env_w + x) * 3;
-  return mk(t[0] * (1.0f / 255.0f), t[1] * (1.0f / 255.0f), t[2] * (1.0f / 255.0f));
+  // texels are stored four bytes apiece (r, g, b, unused): one load
+  const uint32_t t = reinterpret_cast<const uint32_t*>(env)[(size_t)y * sc->env_w + x];
+  return mk((float)(t & 0xffu) * (1.0f / 255.0f), (float)((t >> 8) & 0xffu) * (1.0f / 255.0f),
+            (float)((t >> 16) & 0xffu) * (1.0f / 255.0f));
 }
 
 // What an escaping ray collects when the path is allowed to see emitters

@@ -594,6 +594,16 @@ RRT_DEV bool intersect_sphere(const DeviceSphere& s, const RayPre& r, float* t_o
 template <bool ANY>
 RRT_DEV bool intersect_others(const SceneTables* __restrict__ sc, const RayPre& r, float tmax, int skip_a, int skip_b,
                               Hit* hit) {
+  // most rays end before they come near any of these shapes (a light quad above the scene): the part
+  // of the ray that matters, [0, tmax], against the box around all of them first
+  {
+    const float t0x = (sc->others_bmin[0] - r.o.x) * r.inv.x, t1x = (sc->others_bmax[0] - r.o.x) * r.inv.x;
+    const float t0y = (sc->others_bmin[1] - r.o.y) * r.inv.y, t1y = (sc->others_bmax[1] - r.o.y) * r.inv.y;
+    const float t0z = (sc->others_bmin[2] - r.o.z) * r.inv.z, t1z = (sc->others_bmax[2] - r.o.z) * r.inv.z;
+    const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+    const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+    if (tn > tf * 1.00001f + 1e-6f) return false;  // (a NaN from 0 * inf compares false: the shapes are looked at)
+  }
   bool found = false;
   int code = sc->n_tris;
   for (int i = 0; i < sc->n_rects; ++i, ++code) {
