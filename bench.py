@@ -276,13 +276,17 @@ def main():
                        entry("k_connect", 2, st.rays_shadow, st.launches_extend + st.launches_primary, st.ms_connect)]
             # the dominant kernel by time: k_extend (continuation rays)
             e = kernels[1]
-            # measured with the PMC counters on the default workload (tools/profile_bench.sh): no figure for others
+            # measured with the PMC counters on the default workload (tools/profile_bench.sh, a rocprofv3 --pmc run of its
+            # own: the counters cannot be read inside this run): HBM bytes of one frame's k_extend launches, per launch
+            # of this run; no figure for other workloads
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
             default_workload = args.workload == "buddha" and (args.width, args.height, args.spp) == (1920, 1080, 256)
             if default_workload and os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    per_frame = json.load(f).get("hbm_bytes_per_frame")
+                if per_frame:
+                    traffic = per_frame * args.steps / e["launches"]
             roofline = {"kernel": "k_extend", "bound": "hbm", "achieved": e["algorithmic_gb_per_s"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": e["algorithmic_gb_per_s"] / HBM_PEAK_GBS, "traffic": traffic,
                         "bytes_per_ray": e["bytes_per_ray"], "nodes_per_ray": e["nodes_per_ray"],

@@ -2,7 +2,7 @@
 
     profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
     profiles/<tag>_pmc_summary.json   per-kernel sums of FETCH_SIZE / WRITE_SIZE / TCC_HIT / TCC_MISS
-    profiles/extend_traffic.json      HBM bytes per k_extend launch, read by bench.py
+    profiles/extend_traffic.json      HBM bytes of all k_extend launches of one frame, read by bench.py
 
 FETCH_SIZE and WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes for
 16-byte-per-lane loads (which is what every traversal load is), so it is doubled before use.
@@ -53,10 +53,12 @@ def main(tag):
     with open(os.path.join(dst, tag + "_pmc_summary.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     ext = out.get("rrt::k_extend<false>")
-    if ext and "hbm_bytes_per_launch" in ext:
+    frames = launches.get("rrt::k_primary<false>", 0)  # one primary launch per frame of this workload
+    if ext and "hbm_bytes_per_launch" in ext and frames:
         with open(os.path.join(dst, "extend_traffic.json"), "w") as f:
-            json.dump({"source": tag, "kernel": "k_extend", "hbm_bytes_per_launch": ext["hbm_bytes_per_launch"],
-                       "launches": ext["launches"], "avg_launch_us": ext["avg_launch_us"],
+            json.dump({"source": tag, "kernel": "k_extend", "workload": "buddha 1920x1080, 256 spp",
+                       "hbm_bytes_per_frame": ext["hbm_bytes_per_launch"] * ext["launches"] / frames,
+                       "launches_per_frame": ext["launches"] / frames, "avg_launch_us": ext["avg_launch_us"],
                        "l2_hit_rate": ext.get("l2_hit_rate")}, f, indent=1)
     for name, e in sorted(out.items()):
         print("%-28s launches %4d avg %9.1f us  HBM %8.1f GB/s  L2 hit %.3f" % (
