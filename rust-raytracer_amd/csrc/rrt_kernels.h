@@ -438,6 +438,7 @@ RRT_DEV uint32_t grab_size(uint32_t longest, uint32_t waves) {
 template <bool COUNT>
 struct ExtendJob {
   static constexpr int kDebugRow = 0;  // row of the diagnostic build's counters
+  static constexpr bool kRootTest = false;  // its rays start on surfaces
   const RenderParams& p;
   const SceneTables* sc;  // LDS copy of the shapes
   const uint32_t* lens_c;
@@ -529,6 +530,7 @@ __global__ void __launch_bounds__(kTraceBlock, RRT_EXTEND_WAVES) k_extend(Render
 template <bool COUNT>
 struct PrimaryJob {
   static constexpr int kDebugRow = 2;  // row of the diagnostic build's counters
+  static constexpr bool kRootTest = true;  // its rays may start anywhere
   const RenderParams& p;
   const CameraParams& cam;
   const SceneTables* sc;  // LDS copy of the shapes
@@ -795,6 +797,7 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
 // the clamp; all by one lane, so the sum keeps the order of the reference's loop body.
 struct ConnectJob {
   static constexpr int kDebugRow = 1;  // row of the diagnostic build's counters
+  static constexpr bool kRootTest = false;  // its rays start on surfaces
   const RenderParams& p;
   const SceneTables* sc;  // LDS copy of the shapes
   const uint32_t* lens;
@@ -902,6 +905,7 @@ __global__ void RRT_TRACE_BOUNDS k_connect(RenderParams p) {
 template <bool COUNT>
 struct TailJob {
   static constexpr int kDebugRow = 0;  // row of the diagnostic build's counters
+  static constexpr bool kRootTest = false;  // its rays start on surfaces
   const RenderParams& p;
   const SceneTables* sc;  // LDS copy of all the small tables
   const uint32_t* lens;
@@ -1181,6 +1185,7 @@ __global__ void k_pass_stats(RenderParams p) {
 // ---------------------------------------------------------------- parity hooks
 struct IntersectJob {
   static constexpr int kDebugRow = 0;  // row of the diagnostic build's counters
+  static constexpr bool kRootTest = true;  // its rays may start anywhere
   const TriIsect* tris;
   const SceneTables* sc;
   const float* org_dir;
@@ -1229,6 +1234,7 @@ __global__ void RRT_TRACE_BOUNDS k_intersect(const BvhNode* nodes, const TriIsec
 
 struct OccludedJob {
   static constexpr int kDebugRow = 1;  // row of the diagnostic build's counters
+  static constexpr bool kRootTest = true;  // its rays may start anywhere
   const SceneTables* sc;
   const float* odt;
   uint8_t* out;

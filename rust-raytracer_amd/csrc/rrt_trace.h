@@ -182,6 +182,13 @@ struct Ray {
 #ifndef RRT_LEAF_FRACTION
 #define RRT_LEAF_FRACTION 2
 #endif
+// A job type with kRootTest has its rays tested against the box of the whole hierarchy before they set
+// out: camera rays that pass the model by -- whole waves of them, the samples of one pixel -- then never
+// enter the traversal loop.  (Rays that start on a surface are inside that box; for them the six
+// registers the box takes cost more than the test can save.)
+#ifndef RRT_ROOT_TEST
+#define RRT_ROOT_TEST 1
+#endif
 
 // One inner-node step of a lane: the four child boxes (decoded from the node's 8-bit grid) against
 // the ray, nearest child next, the other children that were hit onto the stack (farthest first, so
@@ -267,6 +274,17 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
   hit.t = INFINITY;
   hit.u = hit.v = 0.0f;
   bool found = false;
+  // The root's grid spans every triangle: origin + [0, 255] steps per axis, padded so that a ray any
+  // child-box test below would let in (those round by a few ulps) is let in here as well.
+  float root_lo[3] = {0.0f, 0.0f, 0.0f}, root_hi[3] = {0.0f, 0.0f, 0.0f};
+  if (RRT_ROOT_TEST && Job::kRootTest && has_tris) {
+    for (int k = 0; k < 3; ++k) {
+      const float extent = 255.0f * __uint_as_float((uint32_t)nodes[0].exp[k] << 23);
+      const float pad = 1e-4f * extent + 1e-30f;
+      root_lo[k] = nodes[0].origin[k] - pad;
+      root_hi[k] = nodes[0].origin[k] + extent + pad;
+    }
+  }
 #ifdef RRT_PHASE_CLOCKS
   unsigned long long dbg[32] = {};
   unsigned long long clk2 = 0;
@@ -301,7 +319,16 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
     found = false;                                           \
     sp = 0;                                                  \
     cur = 0;                                                 \
-    state = has_tris ? kTravelling : kArrived;               \
+    bool enter_ = has_tris;                                  \
+    if (RRT_ROOT_TEST && Job::kRootTest && has_tris) {       \
+      const float ax_ = fmaf(root_lo[0], r.inv.x, -r.ood.x), bx_ = fmaf(root_hi[0], r.inv.x, -r.ood.x); \
+      const float ay_ = fmaf(root_lo[1], r.inv.y, -r.ood.y), by_ = fmaf(root_hi[1], r.inv.y, -r.ood.y); \
+      const float az_ = fmaf(root_lo[2], r.inv.z, -r.ood.z), bz_ = fmaf(root_hi[2], r.inv.z, -r.ood.z); \
+      const float tn_ = fmaxf(fmaxf(fminf(ax_, bx_), fminf(ay_, by_)), fmaxf(fminf(az_, bz_), tmin));   \
+      const float tf_ = fminf(fminf(fmaxf(ax_, bx_), fmaxf(ay_, by_)), fminf(fmaxf(az_, bz_), tmax));   \
+      enter_ = tn_ <= tf_ * 1.0000005f;                      \
+    }                                                        \
+    state = enter_ ? kTravelling : kArrived;                 \
   } while (0)
   // entries pushed before the ray found its current hit may lie beyond it: those are skipped unread
 #define RRT_POP_OR_ARRIVE()                                  \
