@@ -44,6 +44,7 @@ rr = _load("rust_raytracer_amd", "rust-raytracer_amd/__init__.py")
 standin = _load("rust_raytracer_amd.standin", "rust-raytracer_amd/standin.py")
 rrdist = _load("rust_raytracer_amd.distributed", "rust-raytracer_amd/distributed.py")
 stress = _load("rust_raytracer_amd.stress", "rust-raytracer_amd/stress.py")
+rrbuild = _load("rust_raytracer_amd.build", "rust-raytracer_amd/build.py")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # algorithmic bytes per ray: 64 B per BVH node visited (corner, grid exponents, four links, four boxes of six bytes), 36 B per
@@ -279,19 +280,27 @@ def main():
             # measured with the PMC counters on the default workload (tools/profile_bench.sh, a rocprofv3 --pmc run of its
             # own: the counters cannot be read inside this run): HBM bytes of one frame's k_extend launches, per launch
             # of this run; no figure for other workloads
+            # -- and none when the kernel sources have changed since that profile was taken
             traffic = None
+            traffic_note = None
             tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
             default_workload = args.workload == "buddha" and (args.width, args.height, args.spp) == (1920, 1080, 256)
             if default_workload and os.path.exists(tpath):
                 with open(tpath) as f:
-                    per_frame = json.load(f).get("hbm_bytes_per_frame")
-                if per_frame:
+                    prof = json.load(f)
+                per_frame = prof.get("hbm_bytes_per_frame")
+                if prof.get("kernel_fingerprint") != rrbuild.kernel_fingerprint():
+                    traffic_note = "profiles/extend_traffic.json (%s) was taken from other kernel sources than this tree's" % prof.get("source")
+                elif per_frame:
                     traffic = per_frame * args.steps / e["launches"]
+                    traffic_note = "PMC counters of rocprofv3 run %s of this command, same kernel sources" % prof.get("source")
             roofline = {"kernel": "k_extend", "bound": "hbm", "achieved": e["algorithmic_gb_per_s"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": e["algorithmic_gb_per_s"] / HBM_PEAK_GBS, "traffic": traffic,
                         "bytes_per_ray": e["bytes_per_ray"], "nodes_per_ray": e["nodes_per_ray"],
                         "tris_per_ray": e["tris_per_ray"], "launches": e["launches"], "avg_launch_ms": e["avg_launch_ms"],
                         "rays_per_launch": e["rays_per_launch"]}
+            if traffic_note:
+                roofline["traffic_source"] = traffic_note
             if alone_ms:
                 roofline["avg_launch_ms_alone"] = alone_ms
                 roofline["frac_alone"] = roofline["frac"] * e["avg_launch_ms"] / alone_ms

@@ -22,6 +22,17 @@ HOST_SOURCES = ["yaml_lite.cpp", "obj_loader.cpp", "scene.cpp", "camera_film.cpp
 HOST_HEADERS = ["yaml_lite.h", "obj_loader.h", "rrt_host.hpp"]
 
 
+def kernel_fingerprint():
+    """SHA-256 over the sources the device kernels and the hierarchy they walk are compiled from.  A profile
+    summary records it; a reader can tell whether the figures still describe the code in the tree."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(HIP_SOURCES + HIP_HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True

@@ -14,8 +14,13 @@ import json
 import os
 import shutil
 import sys
+import importlib.util
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_spec = importlib.util.spec_from_file_location("rrt_build", os.path.join(ROOT, "rust-raytracer_amd", "build.py"))
+_build = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_build)
+kernel_fingerprint = _build.kernel_fingerprint
 
 
 def main(tag):
@@ -59,7 +64,7 @@ def main(tag):
             json.dump({"source": tag, "kernel": "k_extend", "workload": "buddha 1920x1080, 256 spp",
                        "hbm_bytes_per_frame": ext["hbm_bytes_per_launch"] * ext["launches"] / frames,
                        "launches_per_frame": ext["launches"] / frames, "avg_launch_us": ext["avg_launch_us"],
-                       "l2_hit_rate": ext.get("l2_hit_rate")}, f, indent=1)
+                       "l2_hit_rate": ext.get("l2_hit_rate"), "kernel_fingerprint": kernel_fingerprint()}, f, indent=1)
     for name, e in sorted(out.items()):
         print("%-28s launches %4d avg %9.1f us  HBM %8.1f GB/s  L2 hit %.3f" % (
             name, e["launches"], e["avg_launch_us"], e.get("hbm_gb_per_s", 0.0), e.get("l2_hit_rate", 0.0)))
