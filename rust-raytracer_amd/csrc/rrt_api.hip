@@ -1504,12 +1504,16 @@ std::mutex g_comm_mutex;           // also serialises reduces: a communicator ru
 std::vector<CommSet> g_comm_sets;
 void destroy_comm_sets() {
   std::lock_guard<std::mutex> lock(g_comm_mutex);
+  if (g_comm_sets.empty()) return;
+  int before = -1;
+  if (hipGetDevice(&before) != hipSuccess) before = -1;
   for (CommSet& set : g_comm_sets)
     for (size_t i = 0; i < set.comms.size(); ++i) {
       (void)hipSetDevice(set.devices[i]);
       g_rccl.comm_destroy(set.comms[i]);
     }
   g_comm_sets.clear();
+  if (before >= 0) (void)hipSetDevice(before);
 }
 
 int film_reduce_impl(rrt_ctx** ctxs, int n, int root) {
@@ -1521,6 +1525,12 @@ int film_reduce_impl(rrt_ctx** ctxs, int n, int root) {
     for (int j = 0; j < i; ++j)
       if (devs[i] == devs[j]) return fail(ctxs[i], RRT_E_INVALID, "two contexts on one device: one rank per GPU");
   std::lock_guard<std::mutex> lock(g_comm_mutex);
+  // the calling thread gets its current device back, whichever way this returns
+  struct DeviceGuard {
+    int device = -1;
+    DeviceGuard() { if (hipGetDevice(&device) != hipSuccess) device = -1; }
+    ~DeviceGuard() { if (device >= 0) (void)hipSetDevice(device); }
+  } device_guard;
   CommSet* set = nullptr;
   for (CommSet& s : g_comm_sets)
     if (s.devices == devs) set = &s;
