@@ -343,3 +343,29 @@ def test_refused_threads_change_nothing(rrt):
     finally:
         lib.rrt_debug_fail_threads_after(-1)
     assert len(set(results)) == 1, results
+
+
+def test_rccl_literals_match_the_installed_header():
+    """rrt_film_reduce calls RCCL through dlsym with hand-written prototypes and enum literals: they must be the
+    ones of the rccl.h this image ships (skipped where the header is absent)."""
+    import re
+    header = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(header):
+        pytest.skip("no rccl.h")
+    h = open(header).read()
+    src = open(os.path.join(ROOT, "rust-raytracer_amd", "csrc", "rrt_api.hip")).read()
+    m = re.search(r"const int kFloat32 = (\d+), kSum = (\d+);", src)
+    assert m, "the literals moved: update this test"
+    assert int(m.group(1)) == int(re.search(r"ncclFloat32\s*=\s*(\d+)", h).group(1))
+    assert int(m.group(2)) == int(re.search(r"ncclSum\s*=\s*(\d+)", h).group(1))
+
+    def params(name):
+        decl = re.search(r"ncclResult_t\s+%s\s*\(([^;]*?)\)\s*;" % name, h, re.S).group(1)
+        return [re.sub(r"\s+", " ", p).strip() for p in decl.split(",")]
+    red = params("ncclReduce")
+    assert len(red) == 8 and red[0].startswith("const void*") and red[1].startswith("void*") and red[2].startswith("size_t")
+    assert red[3].startswith("ncclDataType_t") and red[4].startswith("ncclRedOp_t") and red[5].startswith("int ")
+    assert red[6].startswith("ncclComm_t") and "Stream_t" in red[7]
+    init = params("ncclCommInitAll")
+    assert len(init) == 3 and init[0].startswith("ncclComm_t*") and init[1].startswith("int ") and init[2].startswith("const int*")
+    assert len(params("ncclCommDestroy")) == 1
