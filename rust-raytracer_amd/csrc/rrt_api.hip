@@ -1500,6 +1500,7 @@ struct CommSet {
   std::vector<int> devices;
   std::vector<comm_t> comms;
 };
+std::atomic<bool> g_reduce_single_through_rccl{false};  // test hook, see rrt_debug_reduce_single_through_rccl
 std::mutex g_comm_mutex;           // also serialises reduces: a communicator runs one collective at a time
 std::vector<CommSet> g_comm_sets;
 void destroy_comm_sets() {
@@ -1580,13 +1581,18 @@ int rrt_film_reduce(rrt_ctx** ctxs, int n, int root) {
   for (int i = 1; i < n; ++i)
     if (ctxs[i]->film_w != ctxs[0]->film_w || ctxs[i]->film_h != ctxs[0]->film_h)
       return fail(ctxs[i], RRT_E_INVALID, "films differ in size");
-  if (n == 1) return RRT_OK;
+  if (n == 1 && !g_reduce_single_through_rccl.load()) return RRT_OK;
   try {
     return film_reduce_impl(ctxs, n, root);
   } catch (...) {
     return RRT_E_NOMEM;
   }
 }
+
+// Test hook, not part of include/rrt.h: a reduce over a single context normally returns at once; with
+// this on it goes through RCCL like any other (a one-rank communicator: the film comes back unchanged),
+// which lets a machine with one GPU run the library loading, the communicator cache and the collective.
+void rrt_debug_reduce_single_through_rccl(int on) { g_reduce_single_through_rccl.store(on != 0); }
 
 // Test hook, not part of include/rrt.h: after `n` more host threads every further thread creation of
 // the library is refused as if the system had none left (n < 0: back to normal).  The library must

@@ -726,6 +726,39 @@ def test_film_reduce_single_process(rrt, cornell, gpu_ctx):
         other.close()
 
 
+def test_film_reduce_runs_rccl_on_one_gpu(rrt, cornell):
+    """The RCCL path of rrt_film_reduce on a machine with a single GPU: a test hook sends the one-context reduce
+    through the library loading, the communicator cache and ncclReduce (a one-rank communicator), film and
+    first-hit buffers; the buffers must come back unchanged, twice (the second call reuses the communicator),
+    and destroying the context must tear the communicator down without trouble."""
+    import ctypes as C
+    lib = rrt.hip_lib()
+    lib.rrt_debug_reduce_single_through_rccl.argtypes = [C.c_int]
+    lib.rrt_debug_reduce_single_through_rccl.restype = None
+    scene, rs = cornell
+    w = h = 64
+    ctx = rrt.Context(0)
+    try:
+        ctx.upload_scene(scene)
+        ctx.set_camera(rrt.Camera.from_settings(rs, w, h))
+        ctx.film_alloc(w, h)
+        ctx.set_option(rrt.OPT_AOVS, 1)
+        ctx.render(rrt.make_settings(w, h, 4, rs.clamp, seed=3), 0, 4)
+        film = ctx.film_download()
+        normal, albedo = ctx.aov_download()
+        assert film[..., 3].min() == 4.0 and np.abs(film[..., :3]).sum() > 0
+        lib.rrt_debug_reduce_single_through_rccl(1)
+        for _ in range(2):
+            rrt.film_reduce([ctx], 0)
+            np.testing.assert_array_equal(ctx.film_download(), film)
+            n2, a2 = ctx.aov_download()
+            np.testing.assert_array_equal(n2, normal)
+            np.testing.assert_array_equal(a2, albedo)
+    finally:
+        lib.rrt_debug_reduce_single_through_rccl(0)
+        ctx.close()
+
+
 def test_first_hit_and_occlusion_bench_mesh_golden(rrt, gpu_ctx, parity_record):
     """The full-size bench mesh (1,087,716 triangles, what bench.py renders): first hits and any-hit answers
     against the oracle's, committed as a golden file (tests/golden/make_golden.py --large)."""
