@@ -50,17 +50,22 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # algorithmic bytes per ray: 64 B per BVH node visited (corner, grid exponents, four links, four boxes of six bytes), 36 B per
 # triangle tested (nine f32 positions), 32 B ray in, 16 B hit out
 NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 64, 36, 32, 16
+STATE_BYTES_PER_BOUNCE = 264  # wavefront path state read + written per shaded bounce
 
 
-def load_buddha(width, height):
+def load_buddha(width, height, hard=False):
     folder = os.path.join(rr.SCENES, "buddha")
     rs = rr.load_render_settings(folder)
     # the "microfacet" configuration: Plastic -> Lambertian + Trowbridge-Reitz with alpha = 0.27^2
     material = rr.make_material(rr.MAT_PLASTIC, kd=(0.6, 0.6, 0.6), ks=(1.0, 1.0, 1.0), roughness=0.27, ior=1.5)
-    if os.path.exists(os.path.join(folder, "happy-buddha.obj")):
+    if os.path.exists(os.path.join(folder, "happy-buddha.obj")) and not hard:
         scene = rr.Scene.load_from_folder(folder)
         scene.set_material(0, material)
         mesh = "happy-buddha.obj"
+    elif hard:
+        pos, nrm = standin.happy_buddha_hard()
+        scene = rr.Scene.load_from_folder_with_mesh(folder, pos, nrm, material)
+        mesh = "generated stand-in with overhanging tiers, through-holes, hashed triangle order"
     else:
         # RRT_BENCH_MESH_DIVISOR: diagnostic only (coarser stand-in = smaller working set); the bench line is quoted at 1
         div = int(os.environ.get("RRT_BENCH_MESH_DIVISOR", "1"))
@@ -69,6 +74,62 @@ def load_buddha(width, height):
         mesh = "generated stand-in"
     camera = rr.Camera.from_settings(rs, width, height)
     return scene, rs, camera, mesh
+
+
+def make_workload(name, W, H, SPP, spp_label, trios, rank=0):
+    """(scene, render settings or None, camera, mesh label, depth limit, clamp, description) of a named workload."""
+    if name == "stress":
+        t_gen = time.perf_counter()
+        scene, cam_args, depth_limit, clamp = stress.stress_scene(rr, trios)
+        camera = rr.Camera(image_width=W, image_height=H, **cam_args)
+        if rank == 0:
+            print("stress scene generated in %.1f s" % (time.perf_counter() - t_gen), file=sys.stderr, flush=True)
+        return (scene, None, camera, "%d generated trios" % trios, depth_limit, clamp,
+                "stress: %d cow/lamp/teapot trios on a grid, %dx%d, %d spp %s, depth %d, clamp %g, matte, distant + area light" % (
+                    trios, W, H, SPP, spp_label, depth_limit, clamp))
+    if name.startswith("cornell"):
+        # scene/cornell at the frame size and sample count of the second configuration (--spp 1024); "-matte": every
+        # material replaced by Matte with its Kd (the "matte + area light" reading), else the materials as shipped
+        folder = os.path.join(rr.SCENES, "cornell")
+        rs = rr.load_render_settings(folder)
+        scene = rr.Scene.load_from_folder(folder)
+        if name == "cornell-matte":
+            d = scene.desc()
+            for i in range(d.n_materials):
+                m = d.materials[i]
+                scene.set_material(i, rr.make_material(rr.MAT_MATTE, kd=tuple(m.kd), roughness=0.0))
+        camera = rr.Camera.from_settings(rs, W, H)
+        return (scene, rs, camera, "cornell.obj", rs.depth_limit, rs.clamp,
+                "scene/cornell %dx%d, %d spp %s, depth %d, clamp %g, %s, area light" % (
+                    W, H, SPP, spp_label, rs.depth_limit, rs.clamp,
+                    "all materials matte" if name == "cornell-matte" else "materials as shipped"))
+    scene, rs, camera, mesh = load_buddha(W, H, hard=name == "buddha-hard")
+    return (scene, rs, camera, mesh, rs.depth_limit, rs.clamp,
+            "scene/buddha %dx%d, %d spp %s, depth %d, clamp %g, aperture %g, microfacet plastic, "
+            "3 area + distant + environment lights with MIS" % (W, H, SPP, spp_label, rs.depth_limit, rs.clamp, rs.aperture))
+
+
+def host_cpus():
+    """(logical CPUs of the machine, CPUs this process may use).  On a shared box the second is smaller: the
+    cgroup's quota (cpu.max), else the thread count the box exports for worker pools (OMP_NUM_THREADS), else the
+    scheduler affinity mask."""
+    total = os.cpu_count() or 1
+    usable = total
+    try:
+        usable = min(usable, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = min(usable, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    try:
+        usable = min(usable, max(1, int(os.environ.get("OMP_NUM_THREADS", usable))))
+    except ValueError:
+        pass
+    return total, usable
 
 
 def cpu_baseline(scene, rs, width, height, threads, budget_paths, budget_seconds=0.0):
@@ -93,8 +154,10 @@ def cpu_baseline(scene, rs, width, height, threads, budget_paths, budget_seconds
     return {
         "value": st.paths / st.seconds,
         "unit": "samples/s",
-        "cores": int(st.threads_busy),
+        "cores": int(st.threads_busy),          # worker threads that rendered at least one bucket
         "threads_started": int(st.threads),
+        "host_cores": host_cpus()[0],           # logical CPUs of the machine
+        "host_cores_usable": host_cpus()[1],    # of which this process may use (quota / affinity / the box's pool size)
         "buckets": int(st.buckets),
         "kind": "port",
         "sample": "same scene/camera/depth at %dx%d in %d buckets of %dx%d, %d spp (%d camera paths), %.1f s" % (
@@ -113,12 +176,15 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: seconds of oracle work (0 = use --cpu-paths)")
     ap.add_argument("--cpu-paths", type=int, default=0, help="CPU baseline: camera paths when --cpu-seconds is 0 (both 0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline worker threads (0 = every CPU this process may use)")
     ap.add_argument("--batch-samples", type=int, default=0)
     ap.add_argument("--max-slots", type=int, default=0, help="paths in flight (0 = library default: sized from free device memory)")
     ap.add_argument("--no-calibrate", action="store_true")
-    ap.add_argument("--workload", choices=["buddha", "stress", "cornell", "cornell-matte"], default="buddha",
-                    help="buddha: the headline configuration; stress: cow/lamp/teapot trios on a grid (depth 16)")
+    ap.add_argument("--workload", choices=["buddha", "buddha-hard", "stress", "cornell", "cornell-matte"], default="buddha",
+                    help="buddha: the headline configuration; buddha-hard: the same with the stand-in mesh that has overhanging "
+                         "tiers, through-holes and hashed triangle order; stress: cow/lamp/teapot trios on a grid (depth 16)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the extra lines the default run adds under other_workloads (cornell 1080p / 1024 spp, buddha-hard)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --spp samples per pixel on EVERY GPU (rank r renders [r spp, (r+1) spp)); strong: --spp in total, "
                          "rank r renders [r spp / N, (r+1) spp / N) (the 3840x2160, 4096 spp configuration: --scaling strong "
@@ -146,37 +212,7 @@ def main():
 
     W, H, SPP = args.width, args.height, args.spp
     spp_label = "per GPU" if args.scaling == "weak" else "in total over all GPUs"
-    if args.workload == "stress":
-        t_gen = time.perf_counter()
-        scene, cam_args, depth_limit, clamp = stress.stress_scene(rr, args.trios)
-        camera = rr.Camera(image_width=W, image_height=H, **cam_args)
-        mesh = "%d generated trios" % args.trios
-        workload = "stress: %d cow/lamp/teapot trios on a grid, %dx%d, %d spp %s, depth %d, clamp %g, matte, distant + area light" % (
-            args.trios, W, H, SPP, spp_label, depth_limit, clamp)
-        rs = None
-        if rank == 0:
-            print("stress scene generated in %.1f s" % (time.perf_counter() - t_gen), file=sys.stderr, flush=True)
-    elif args.workload.startswith("cornell"):
-        # scene/cornell at the frame size and sample count of the second configuration (--spp 1024); "-matte": every
-        # material replaced by Matte with its Kd (the "matte + area light" reading), else the materials as shipped
-        folder = os.path.join(rr.SCENES, "cornell")
-        rs = rr.load_render_settings(folder)
-        scene = rr.Scene.load_from_folder(folder)
-        if args.workload == "cornell-matte":
-            d = scene.desc()
-            for i in range(d.n_materials):
-                m = d.materials[i]
-                scene.set_material(i, rr.make_material(rr.MAT_MATTE, kd=tuple(m.kd), roughness=0.0))
-        camera = rr.Camera.from_settings(rs, W, H)
-        mesh = "cornell.obj"
-        depth_limit, clamp = rs.depth_limit, rs.clamp
-        workload = "scene/cornell %dx%d, %d spp %s, depth %d, clamp %g, %s, area light" % (
-            W, H, SPP, spp_label, depth_limit, clamp, "all materials matte" if args.workload == "cornell-matte" else "materials as shipped")
-    else:
-        scene, rs, camera, mesh = load_buddha(W, H)
-        depth_limit, clamp = rs.depth_limit, rs.clamp
-        workload = ("scene/buddha %dx%d, %d spp %s, depth %d, clamp %g, aperture %g, microfacet plastic, "
-                    "3 area + distant + environment lights with MIS" % (W, H, SPP, spp_label, depth_limit, clamp, rs.aperture))
+    scene, rs, camera, mesh, depth_limit, clamp, workload = make_workload(args.workload, W, H, SPP, spp_label, args.trios, rank)
     ctx = rr.Context(local_rank)
     if os.environ.get("RRT_DEVICE_BVH_OVERRIDE"):  # diagnostic: 0 host build, 1 device build (default: by triangle count)
         ctx.set_option(rr.OPT_DEVICE_BVH, int(os.environ["RRT_DEVICE_BVH_OVERRIDE"]))
@@ -201,58 +237,68 @@ def main():
         s_begin, s_end = rrdist.weak_sample_range(rank, SPP)
     total_spp = SPP if args.scaling == "strong" else SPP * world
 
-    def step():
-        film.zero_()
-        ctx.render(settings, s_begin, s_end)
-        rrdist.reduce_film(film, dst=0)  # RCCL sum onto rank 0; a no-op on one GPU
-
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # ---- calibration (untimed): nodes / triangles fetched per ray of each traversal kernel, for the
-    # roofline's algorithmic bytes (a counting build of the same kernels; per-ray means do not depend on spp)
-    per_ray = None
-    if rank == 0 and not args.no_calibrate:
+    def calibrate(settings, s_begin, s_end):
+        """Untimed: nodes / triangles fetched per ray of each traversal kernel and the share of rays that go into the
+        hierarchy at all, for the roofline's algorithmic bytes (a counting build of the same kernels; per-ray means
+        do not depend on spp)."""
         ctx.set_option(rr.OPT_COUNT_TRAVERSAL, 1)
         ctx.reset_stats()
         film.zero_()
         ctx.render(settings, s_begin, s_begin + min(8, s_end - s_begin))
         st = ctx.stats()
         rays = (st.rays_primary, st.rays_extend - st.rays_primary, st.rays_shadow)
-        per_ray = [(st.nodes_by_kernel[k] / max(rays[k], 1), st.tris_by_kernel[k] / max(rays[k], 1)) for k in range(3)]
+        per_ray = [(st.nodes_by_kernel[k] / max(rays[k], 1), st.tris_by_kernel[k] / max(rays[k], 1),
+                    st.rays_entered_by_kernel[k] / max(rays[k], 1)) for k in range(3)]
         ctx.set_option(rr.OPT_COUNT_TRAVERSAL, 0)
+        return per_ray
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ctx.set_option(rr.OPT_TIMING, 1)
-    ctx.reset_stats()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(settings, s_begin, s_end, steps, warmup, reduce=True):
+        """`warmup` untimed steps, then `steps` timed ones between fences; returns (seconds, stats of the timed steps)."""
+        def step():
+            film.zero_()
+            ctx.render(settings, s_begin, s_end)
+            if reduce:
+                rrdist.reduce_film(film, dst=0)  # RCCL sum onto rank 0; a no-op on one GPU
+        for _ in range(warmup):
+            step()
+        fence()
+        ctx.set_option(rr.OPT_TIMING, 1)
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        seconds = time.perf_counter() - t0
+        st = ctx.stats()
+        ctx.set_option(rr.OPT_TIMING, 0)
+        return seconds, st
+
+    per_ray = calibrate(settings, s_begin, s_end) if rank == 0 and not args.no_calibrate else None
+    elapsed, st = timed(settings, s_begin, s_end, args.steps, args.warmup)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    st = ctx.stats()
     # untimed: one more frame with every kernel on the one stream, for the dominant kernel's launch time when it
     # has the GPU to itself (in the timed frames it shares it with the previous iteration's visibility rays)
     alone_ms = None
     if rank == 0 and not args.no_calibrate:
         keep = film.clone()
         ctx.set_option(rr.OPT_SIDE_STREAM, 0)
+        ctx.set_option(rr.OPT_TIMING, 1)
         ctx.reset_stats()
         ctx.render(settings, s_begin, s_end)
         torch.cuda.synchronize(device)
         st1 = ctx.stats()
         alone_ms = st1.ms_extend / max(st1.launches_extend, 1)
         ctx.set_option(rr.OPT_SIDE_STREAM, 1)
+        ctx.set_option(rr.OPT_TIMING, 0)
         film.copy_(keep)
-    ctx.set_option(rr.OPT_TIMING, 0)
 
     paths_all = float(W) * H * total_spp * args.steps
     value = paths_all / elapsed
@@ -264,46 +310,68 @@ def main():
         assert abs(fsum[3] - float(W) * H * total_spp) < 1e-3 * W * H * total_spp, fsum
         assert all(x == x and x > 0 for x in fsum[:3]), fsum
         roofline = None
+        roofline_shade = None
         kernels = None
+        rays_traversed = None
+        default_workload = args.workload == "buddha" and (args.width, args.height, args.spp) == (1920, 1080, 256)
+        # measured with the PMC counters on the default workload (tools/profile_bench.sh, rocprofv3 --pmc runs of their
+        # own: the counters cannot be read inside this run): HBM bytes and L2 hit rate per kernel over one frame; no
+        # figure for other workloads -- and none when the kernel sources have changed since that profile was taken
+        prof, prof_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
+        if default_workload and os.path.exists(tpath):
+            with open(tpath) as f:
+                prof = json.load(f)
+            if prof.get("kernel_fingerprint") != rrbuild.kernel_fingerprint():
+                prof_note = "profiles/extend_traffic.json (%s) was taken from other kernel sources than this tree's" % prof.get("source")
+                prof = None
+            else:
+                prof_note = "PMC counters of rocprofv3 run %s of this command, same kernel sources" % prof.get("source")
         if per_ray is not None and st.launches_extend:
             def entry(name, k, n_rays, launches, ms):
                 bytes_per_ray = per_ray[k][0] * NODE_BYTES + per_ray[k][1] * TRI_BYTES + RAY_BYTES + HIT_BYTES
                 gbs = n_rays * bytes_per_ray / (ms * 1e-3) * 1e-9 if ms > 0 else 0.0
                 return {"kernel": name, "rays_per_launch": n_rays / max(launches, 1), "bytes_per_ray": bytes_per_ray,
-                        "nodes_per_ray": per_ray[k][0], "tris_per_ray": per_ray[k][1], "launches": int(launches),
-                        "avg_launch_ms": ms / max(launches, 1), "algorithmic_gb_per_s": gbs}
+                        "nodes_per_ray": per_ray[k][0], "tris_per_ray": per_ray[k][1], "share_of_rays_entering_the_hierarchy": per_ray[k][2],
+                        "launches": int(launches), "avg_launch_ms": ms / max(launches, 1), "algorithmic_gb_per_s": gbs,
+                        "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
             kernels = [entry("k_primary", 0, st.rays_primary, st.launches_primary, st.ms_primary),
                        entry("k_extend", 1, st.rays_extend - st.rays_primary, st.launches_extend, st.ms_extend),
                        entry("k_connect", 2, st.rays_shadow, st.launches_extend + st.launches_primary, st.ms_connect)]
+            # rays that did more than fail the test against the box around the model
+            rays_traversed = (st.rays_primary * per_ray[0][2] + (st.rays_extend - st.rays_primary) * per_ray[1][2] +
+                              st.rays_shadow * per_ray[2][2])
             # the dominant kernel by time: k_extend (continuation rays)
             e = kernels[1]
-            # measured with the PMC counters on the default workload (tools/profile_bench.sh, a rocprofv3 --pmc run of its
-            # own: the counters cannot be read inside this run): HBM bytes of one frame's k_extend launches, per launch
-            # of this run; no figure for other workloads
-            # -- and none when the kernel sources have changed since that profile was taken
-            traffic = None
-            traffic_note = None
-            tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
-            default_workload = args.workload == "buddha" and (args.width, args.height, args.spp) == (1920, 1080, 256)
-            if default_workload and os.path.exists(tpath):
-                with open(tpath) as f:
-                    prof = json.load(f)
-                per_frame = prof.get("hbm_bytes_per_frame")
-                if prof.get("kernel_fingerprint") != rrbuild.kernel_fingerprint():
-                    traffic_note = "profiles/extend_traffic.json (%s) was taken from other kernel sources than this tree's" % prof.get("source")
-                elif per_frame:
-                    traffic = per_frame * args.steps / e["launches"]
-                    traffic_note = "PMC counters of rocprofv3 run %s of this command, same kernel sources" % prof.get("source")
+            traffic = l2 = hbm_gbs = None
+            if prof is not None and prof.get("hbm_bytes_per_frame"):
+                traffic = prof["hbm_bytes_per_frame"] * args.steps / e["launches"]
+                l2 = prof.get("l2_hit_rate")
+                hbm_gbs = traffic / (e["avg_launch_ms"] * 1e-3) * 1e-9
             roofline = {"kernel": "k_extend", "bound": "hbm", "achieved": e["algorithmic_gb_per_s"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": e["algorithmic_gb_per_s"] / HBM_PEAK_GBS, "traffic": traffic,
+                        "hbm_gb_per_s": hbm_gbs, "l2_hit_rate": l2,
                         "bytes_per_ray": e["bytes_per_ray"], "nodes_per_ray": e["nodes_per_ray"],
                         "tris_per_ray": e["tris_per_ray"], "launches": e["launches"], "avg_launch_ms": e["avg_launch_ms"],
                         "rays_per_launch": e["rays_per_launch"]}
-            if traffic_note:
-                roofline["traffic_source"] = traffic_note
+            if prof_note:
+                roofline["traffic_source"] = prof_note
             if alone_ms:
                 roofline["avg_launch_ms_alone"] = alone_ms
                 roofline["frac_alone"] = roofline["frac"] * e["avg_launch_ms"] / alone_ms
+        if st.ms_shade > 0:
+            # shade streams path state: per shaded bounce 2 x (ray 32 + throughput 12 + radiance 12 + pixel / flags 8 +
+            # rng 8 + hit 16 + shadow ray 44) = 264 algorithmic bytes
+            gbs = st.path_bounces * STATE_BYTES_PER_BOUNCE / (st.ms_shade * 1e-3) * 1e-9
+            roofline_shade = {"kernel": "k_shade", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": gbs / HBM_PEAK_GBS, "bytes_per_bounce": STATE_BYTES_PER_BOUNCE,
+                              "bounces_per_step": st.path_bounces / args.steps, "ms_per_step": st.ms_shade / args.steps,
+                              "traffic": None, "hbm_gb_per_s": None, "l2_hit_rate": None}
+            k = (prof or {}).get("kernels", {}).get("k_shade")
+            if k:
+                roofline_shade["traffic"] = k["hbm_bytes_per_frame"]   # per step (one frame), all its launches
+                roofline_shade["hbm_gb_per_s"] = k["hbm_bytes_per_frame"] / (st.ms_shade / args.steps * 1e-3) * 1e-9
+                roofline_shade["l2_hit_rate"] = k.get("l2_hit_rate")
         out = {
             "metric": "camera-path samples/sec",
             "value": value,
@@ -322,6 +390,8 @@ def main():
                        "sharding": "sample index ranges per GPU", "samples_per_pixel_total": total_spp,
                        "samples_per_pixel_this_rank": s_end - s_begin},
             "mrays_per_s": rays_rank * world / elapsed * 1e-6,
+            # without the camera rays that only failed the test against the box around the model
+            "mrays_per_s_traversed": rays_traversed * world / elapsed * 1e-6 if rays_traversed is not None else None,
             "rays_per_path": rays_rank / float(st.paths) if st.paths else None,
             "bounces_per_path": st.path_bounces / float(st.paths) if st.paths else None,
             "kernel_ms_per_step": {"primary": st.ms_primary / args.steps, "start": st.ms_raygen / args.steps,
@@ -329,14 +399,35 @@ def main():
                                    "shade": st.ms_shade / args.steps, "connect": st.ms_connect / args.steps,
                                    "film": st.ms_film / args.steps, "tail": st.ms_tail / args.steps},
             "roofline": roofline,
+            "roofline_shade": roofline_shade,
             "traversal_kernels": kernels,
         }
         if world == 1 and rs is not None and (args.cpu_paths > 0 or args.cpu_seconds > 0):
-            out["cpu_baseline"] = cpu_baseline(scene, rs, W, H, args.cpu_threads, args.cpu_paths, args.cpu_seconds)
-            out["cpu_baseline"]["all_threads_busy"] = out["cpu_baseline"]["cores"] == min(args.cpu_threads, out["cpu_baseline"]["buckets"])
+            threads = args.cpu_threads or host_cpus()[1]
+            out["cpu_baseline"] = cpu_baseline(scene, rs, W, H, threads, args.cpu_paths, args.cpu_seconds)
+            out["cpu_baseline"]["all_threads_busy"] = out["cpu_baseline"]["cores"] == min(threads, out["cpu_baseline"]["buckets"])
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
+        # ---- the other single-GPU configurations, on the same context: a few frames each, untimed parts left out
+        if world == 1 and default_workload and not args.no_other_workloads:
+            others = {}
+            for key, name, spp_o, steps_o in (("cornell_1080p_1024spp", "cornell", 1024, 2), ("buddha_hard_standin_1080p_256spp", "buddha-hard", 256, 5)):
+                scene_o, rs_o, camera_o, mesh_o, depth_o, clamp_o, workload_o = make_workload(name, W, H, spp_o, "per GPU", args.trios)
+                ctx.upload_scene(scene_o)
+                ctx.set_camera(camera_o)
+                settings_o = rr.make_settings(W, H, depth_o, clamp_o, seed=0)
+                seconds, st_o = timed(settings_o, 0, spp_o, steps_o, 1, reduce=False)
+                rays_o = st_o.rays_extend + st_o.rays_shadow
+                others[key] = {"workload": workload_o, "mesh": mesh_o, "triangles": int(scene_o.desc().n_tris), "steps": steps_o, "warmup": 1,
+                               "value": float(W) * H * spp_o * steps_o / seconds, "unit": "samples/s",
+                               "ms_per_step": seconds / steps_o * 1e3, "mrays_per_s": rays_o / seconds * 1e-6,
+                               "rays_per_path": rays_o / float(st_o.paths), "bounces_per_path": st_o.path_bounces / float(st_o.paths),
+                               "kernel_ms_per_step": {"primary": st_o.ms_primary / steps_o, "start": st_o.ms_raygen / steps_o,
+                                                      "extend": st_o.ms_extend / steps_o, "shade": st_o.ms_shade / steps_o,
+                                                      "connect": st_o.ms_connect / steps_o, "film": st_o.ms_film / steps_o,
+                                                      "tail": st_o.ms_tail / steps_o}}
+            out["other_workloads"] = others
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -160,6 +160,10 @@ typedef struct rrt_stats {
   uint64_t rays_primary;     /* closest-hit queries made by the primary kernels (part of rays_extend) */
   double ms_tail;            /* kernel time of the tail kernels (RRT_OPT_TAIL_PATHS) */
   uint64_t launches_tail;
+  /* rays per traversal kernel (as nodes_by_kernel) that passed the test against the box around all triangles
+   * and went into the hierarchy; counted only while RRT_OPT_COUNT_TRAVERSAL is on.  Camera rays that look
+   * past the model never get this far. */
+  uint64_t rays_entered_by_kernel[3];
 } rrt_stats;
 
 /* Number of visible HIP devices, or a negative code. */
@@ -223,12 +227,16 @@ int rrt_film_reduce(rrt_ctx** ctxs, int n, int root);  /* (and the first-hit buf
 
 /* check_intersect_scene (src/renderer.rs:213-249) for n rays given as host
  * [n][6] = origin xyz, direction xyz: object id of the closest hit (-1 = miss)
- * and its distance. */
+ * and its distance.  Which object: the f32 traversal the renderer uses.  The
+ * distance: that one object evaluated once more in f64 by the reference's own
+ * formulas (objects/triangle.rs:119-181 on the f32 vertices as uploaded,
+ * rectangle.rs:58-71, plane.rs:45-57, sphere.rs:116-151), rounded to f32. */
 int rrt_intersect(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_t* prim_id, float* t);
 
 /* rrt_intersect without any allocation.  Has no counterpart in the reference: it is for callers that
- * cannot allocate device memory where they call -- code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc.  Same arguments and results as rrt_intersect, but the staging of
+ * cannot allocate device memory where they call -- tight serving loops, harnesses that forbid hipMalloc,
+ * code that must not disturb a memory pool.  (Not for use inside a HIP graph capture: like rrt_intersect
+ * it copies to and from host arrays and waits for the stream.)  Same arguments and results as rrt_intersect, but the staging of
  * the rays, of the results and the kernel's job cursor live in a static device array of the library
  * (2 MiB + 256 B per GPU, held until the process ends) instead of buffers allocated per call, so n is
  * limited: more than RRT_NOALLOC_MAX_RAYS rays are rejected with RRT_E_UNSUPPORTED.  The call makes

@@ -164,6 +164,7 @@ pub struct RrtStats {
     pub rays_primary: u64,
     pub ms_tail: f64,
     pub launches_tail: u64,
+    pub rays_entered_by_kernel: [u64; 3],
 }
 
 #[link(name = "rrt_hip")]

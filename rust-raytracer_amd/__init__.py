@@ -74,7 +74,8 @@ class Stats(C.Structure):
                 ("bvh_nodes", C.c_uint64), ("bvh_bytes", C.c_uint64),
                 ("nodes_by_kernel", C.c_uint64 * 3), ("tris_by_kernel", C.c_uint64 * 3),
                 ("ms_primary", C.c_double), ("launches_primary", C.c_uint64), ("rays_primary", C.c_uint64),
-                ("ms_tail", C.c_double), ("launches_tail", C.c_uint64)]
+                ("ms_tail", C.c_double), ("launches_tail", C.c_uint64),
+                ("rays_entered_by_kernel", C.c_uint64 * 3)]
 
 
 class RenderSettingsFile(C.Structure):

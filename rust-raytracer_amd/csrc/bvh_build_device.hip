@@ -160,8 +160,12 @@ __device__ __forceinline__ float half_area(const float* mn, const float* mx) {
 }
 
 // Nearest neighbour of every cluster among the kRadius clusters on either side: smallest surface
-// of the union, the lower index at equal surface (a consistent order: some pair always chooses
-// each other, so every round merges at least one).
+// of the union.  Equal surfaces (runs of coincident or zero-area triangles, strips of equal boxes)
+// are ordered by a key of the unordered pair {i, j}: the distance |i - j|, then whether the lower
+// index is odd, then the lower index.  Any strict order of the pairs makes the smallest pair choose
+// each other, so every round merges at least one; this one makes a run of equal surfaces pair up as
+// (0,1), (2,3), ... and halve per round, where "the lower index wins" would merge one pair per round
+// and build a tree as deep as the run is long.
 __global__ void __launch_bounds__(kBuildBlock) k_nearest(const uint32_t* __restrict__ cid, uint32_t n_c,
                                                          const PNode* __restrict__ nodes, uint32_t* __restrict__ nn) {
   __shared__ float4 smn[kBuildBlock + 2 * kRadius], smx[kBuildBlock + 2 * kRadius];
@@ -183,6 +187,7 @@ __global__ void __launch_bounds__(kBuildBlock) k_nearest(const uint32_t* __restr
   const float4 mn = smn[threadIdx.x + kRadius], mx = smx[threadIdx.x + kRadius];
   float best = INFINITY;
   int best_j = -1;
+  uint32_t best_tie = 0;
 #pragma unroll
   for (int d = -kRadius; d <= kRadius; ++d) {
     if (d == 0) continue;
@@ -192,9 +197,11 @@ __global__ void __launch_bounds__(kBuildBlock) k_nearest(const uint32_t* __restr
     const float lo[3] = {fminf(mn.x, a.x), fminf(mn.y, a.y), fminf(mn.z, a.z)};
     const float hi[3] = {fmaxf(mx.x, b.x), fmaxf(mx.y, b.y), fmaxf(mx.z, b.z)};
     const float area = half_area(lo, hi);
-    if (area < best || best_j < 0) {  // (j ascends: the first of equal areas stays)
+    const uint32_t tie = ((uint32_t)(d < 0 ? -d : d) << 1) | ((uint32_t)(d < 0 ? j : i) & 1u);
+    if (best_j < 0 || area < best || (area == best && tie < best_tie)) {  // (j ascends: of equal keys the lower j stays)
       best = area;
       best_j = j;
+      best_tie = tie;
     }
   }
   nn[i] = (uint32_t)best_j;
@@ -541,7 +548,17 @@ int build_bvh_device(const float* tri_pos, const float* tri_nrm, const uint32_t*
   std::vector<uint32_t> round_begin;  // first node id made in each round; round_begin.back() = one past the last node
   uint32_t n_c = n, next_node = n;
   int cur = 0;
+  // Meshes take 70-120 rounds (a round merges a third to a half of the clusters at first, fewer near the top).
+  // Input on which the clustering crawls -- a round costs three kernels, a scan and a synchronisation, and
+  // the tree comes out as deep as the rounds are many -- is left to the host builder.
+  uint32_t log2n = 0;
+  while ((1ull << log2n) < n) ++log2n;
+  const size_t max_rounds = 16 * (size_t)log2n + 64;
   while (n_c > 1) {
+    if (round_begin.size() >= max_rounds) {
+      *error = "device BVH build: clustering takes too many rounds (degenerate input)";
+      return RRT_E_UNSUPPORTED;
+    }
     hipLaunchKernelGGL(k_nearest, dim3(blocks_for(n_c)), dim3(kBuildBlock), 0, stream, d_cid[cur], n_c, d_pnodes, d_nn);
     hipLaunchKernelGGL(k_pair_flags, dim3(blocks_for(n_c)), dim3(kBuildBlock), 0, stream, d_nn, n_c, d_flags);
     BUILD_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan, scan_bytes, d_flags, d_scanned, (int)n_c, stream));

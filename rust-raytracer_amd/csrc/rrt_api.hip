@@ -114,12 +114,17 @@ struct rrt_ctx {
   DeviceMaterial* d_materials = nullptr;
   SceneTables* d_scene = nullptr;
   uint8_t* d_env = nullptr;
+  float* d_tri_pos = nullptr;      // scene order, as uploaded: what rrt_intersect computes its distances from
+  ShapesF64* d_exact = nullptr;    // f64 parameters of the analytic shapes, for the same purpose
   SceneTables h_scene;
   uint32_t n_nodes = 0;
   uint64_t bvh_bytes = 0;
   uint32_t n_tris = 0, bvh_max_depth = 0;
   bool bvh_built_on_device = false;
   double bvh_build_seconds = 0.0;   // device build only
+  std::string bvh_fallback_reason;  // why the automatic mode built on the host after all (empty: it did not)
+  bool debug_fail_device_bvh = false;        // RRT_DEBUG_FAIL_DEVICE_BVH in the environment at rrt_create: every device build fails
+  bool debug_reduce_through_rccl = false;    // RRT_DEBUG_REDUCE_SINGLE_THROUGH_RCCL at rrt_create: see rrt_film_reduce
   int device_bvh = 2;               // RRT_OPT_DEVICE_BVH: 0 host build, 1 device build, 2 by triangle count
 
   // camera
@@ -169,9 +174,29 @@ struct rrt_ctx {
 
 namespace {
 
+// Test switch, environment only (no exported function): RRT_DEBUG_FAIL_THREADS_AFTER=n refuses every host
+// thread creation of the builder after the first n, as if the system had none left; the work then runs
+// on the thread that asked.  Read where a build starts; absent (the normal case): never refuse.
+void thread_switch_from_environment() {
+  const char* v = std::getenv("RRT_DEBUG_FAIL_THREADS_AFTER");
+  g_thread_creations_allowed.store(v ? std::max(-1, std::atoi(v)) : -1);
+}
+
 int fail(rrt_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->error = msg;
   else g_create_error = msg;
+  return code;
+}
+
+// For handlers of std::bad_alloc: the message goes into storage the string already owns when it can (assign
+// may reuse the capacity), and a second failure leaves the previous message rather than throwing again.
+int fail_static(rrt_ctx* ctx, int code, const char* msg) noexcept {
+  try {
+    if (ctx) ctx->error.assign(msg);
+    else g_create_error.assign(msg);
+  } catch (...) {
+    if (ctx) ctx->error.clear();
+  }
   return code;
 }
 
@@ -194,6 +219,10 @@ void free_scene(rrt_ctx* ctx) {
   (void)hipFree(ctx->d_materials);
   (void)hipFree(ctx->d_scene);
   (void)hipFree(ctx->d_env);
+  (void)hipFree(ctx->d_tri_pos);
+  (void)hipFree(ctx->d_exact);
+  ctx->d_tri_pos = nullptr;
+  ctx->d_exact = nullptr;
   ctx->d_nodes = nullptr;
   ctx->d_tris = nullptr;
   ctx->d_tri_shade = nullptr;
@@ -589,6 +618,10 @@ rrt_ctx* rrt_create(int device) {
   }
   ctx->device = device;
   ctx->debug_pending = std::getenv("RRT_DEBUG_PENDING") != nullptr;
+  // Two more switches for tests, read once per context, never exported as functions: a context created with
+  // them in the environment behaves differently, every other context of the process does not.
+  ctx->debug_fail_device_bvh = std::getenv("RRT_DEBUG_FAIL_DEVICE_BVH") != nullptr;
+  ctx->debug_reduce_through_rccl = std::getenv("RRT_DEBUG_REDUCE_SINGLE_THROUGH_RCCL") != nullptr;
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&ctx->d_stats, sizeof(DeviceStats)) != hipSuccess ||
       hipMalloc((void**)&ctx->d_work, sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess) {
@@ -666,16 +699,50 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   if (rc != RRT_OK) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   free_scene(ctx);
+  thread_switch_from_environment();
 
-  // ---- BVH over the triangles, then the leaf-ordered records: on the host here, or by kernels further down
-  const bool device_build = sd->n_tris >= kDeviceBuildMinTris &&
-                            (ctx->device_bvh == 1 || (ctx->device_bvh == 2 && sd->n_tris >= kAutoDeviceBuildTris));
+  // ---- BVH over the triangles and the leaf-ordered records: by kernels, or on the host.  In the automatic
+  // mode a device build that fails (out of device memory for its ~290 B per triangle of temporaries, a
+  // clustering that stops making progress on degenerate input, a tree too deep for the traversal stack)
+  // is not the end of the upload: the host's binned-SAH build is depth-bounded and needs no device memory
+  // beyond the result, so it runs instead.  Only an explicit RRT_OPT_DEVICE_BVH = 1 reports the failure.
+  bool device_build = sd->n_tris >= kDeviceBuildMinTris &&
+                      (ctx->device_bvh == 1 || (ctx->device_bvh == 2 && sd->n_tris >= kAutoDeviceBuildTris));
+  uint32_t device_depth = 0, device_nodes = 0;
+  ctx->bvh_build_seconds = 0.0;
+  ctx->bvh_fallback_reason.clear();
+  if (device_build) {
+    DeviceBvhResult built;
+    std::string why;
+    rc = ctx->debug_fail_device_bvh ? RRT_E_NOMEM : build_bvh_device(sd->tri_pos, sd->tri_nrm, sd->tri_mat, sd->n_tris, ctx->stream, &built, &why);
+    if (ctx->debug_fail_device_bvh) why = "device build refused by RRT_DEBUG_FAIL_DEVICE_BVH";
+    if (rc == RRT_OK && 3ull * built.max_depth + 1 > (uint64_t)kStackDepth) {
+      rc = RRT_E_UNSUPPORTED;
+      why = "hierarchy too deep for the traversal stack";
+    }
+    ctx->d_nodes = built.d_nodes;  // (free_scene releases them)
+    ctx->d_tris = built.d_tris;
+    ctx->d_tri_shade = built.d_tri_shade;
+    if (rc != RRT_OK) {
+      free_scene(ctx);
+      if (ctx->device_bvh == 1) return fail(ctx, rc, why);
+      ctx->bvh_fallback_reason = why;
+      device_build = false;
+    } else {
+      device_depth = built.max_depth;
+      device_nodes = built.n_nodes;
+      ctx->bvh_build_seconds = built.seconds;
+      if (std::getenv("RRT_BVH_TIMING"))
+        std::fprintf(stderr, "bvh build on the device: %u triangles, %u clustering rounds, %u 4-wide nodes, depth %u, %.3f s\n", sd->n_tris,
+                     built.rounds, built.n_nodes, built.max_depth, built.seconds);
+    }
+  }
   BvhBuildResult bvh;
   struct BvhOwner {  // frees the hierarchy on every way out (free_bvh leaves it empty, so the explicit calls below are harmless)
     BvhBuildResult* b;
     ~BvhOwner() { free_bvh(b); }
   } bvh_owner{&bvh};
-  if (!device_build && !build_bvh(sd->tri_pos, sd->n_tris, 0, &bvh)) return fail(ctx, RRT_E_NOMEM, "BVH build: out of host memory");
+  if (!device_build && !build_bvh(sd->tri_pos, sd->n_tris, 0, &bvh)) { free_scene(ctx); return fail(ctx, RRT_E_NOMEM, "BVH build: out of host memory"); }
   // (malloc'ed, not vectors: 100 bytes per triangle that need no zeroing first)
   TriIsect* tris = device_build ? nullptr : (TriIsect*)std::malloc(sizeof(TriIsect) * std::max<size_t>(sd->n_tris, 1));
   TriShade* shade = device_build ? nullptr : (TriShade*)std::malloc(sizeof(TriShade) * std::max<size_t>(sd->n_tris, 1));
@@ -780,11 +847,13 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
     } else if (l.kind == RRT_LIGHT_INFINITE) {
       if (!sd->env_rgb8 || !sd->env_w || !sd->env_h) {
         free_bvh(&bvh);
+        free_scene(ctx);
         return fail(ctx, RRT_E_INVALID, "infinite light without environment texels");
       }
       st.infinite_light = (int)i;
     } else if (l.kind != RRT_LIGHT_POINT) {
       free_bvh(&bvh);
+      free_scene(ctx);
       return fail(ctx, RRT_E_INVALID, "unknown light kind");
     }
   }
@@ -816,28 +885,9 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   std::vector<DeviceMaterial> mats(sd->n_materials);
   for (uint32_t i = 0; i < sd->n_materials; ++i) mats[i] = digest_material(sd->materials[i]);
 
-  uint32_t max_depth = bvh.max_depth;
-  ctx->n_nodes = bvh.n_nodes;
+  const uint32_t max_depth = device_build ? device_depth : bvh.max_depth;
+  ctx->n_nodes = device_build ? device_nodes : bvh.n_nodes;
   ctx->bvh_built_on_device = device_build;
-  ctx->bvh_build_seconds = 0.0;
-  if (device_build) {
-    DeviceBvhResult built;
-    std::string why;
-    rc = build_bvh_device(sd->tri_pos, sd->tri_nrm, sd->tri_mat, sd->n_tris, ctx->stream, &built, &why);
-    ctx->d_nodes = built.d_nodes;  // (free_scene releases them on the error paths below)
-    ctx->d_tris = built.d_tris;
-    ctx->d_tri_shade = built.d_tri_shade;
-    if (rc != RRT_OK) {
-      free_scene(ctx);
-      return fail(ctx, rc, why);
-    }
-    max_depth = built.max_depth;
-    ctx->n_nodes = built.n_nodes;
-    ctx->bvh_build_seconds = built.seconds;
-    if (std::getenv("RRT_BVH_TIMING"))
-      std::fprintf(stderr, "bvh build on the device: %u triangles, %u clustering rounds, %u 4-wide nodes, depth %u, %.3f s\n", sd->n_tris,
-                   built.rounds, built.n_nodes, built.max_depth, built.seconds);
-  }
   // every 4-wide node on a ray's way down leaves at most 3 entries on the traversal stack
   if (3ull * max_depth + 1 > (uint64_t)kStackDepth) {
     free_bvh(&bvh);
@@ -855,6 +905,8 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   }
   if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_materials, sd->n_materials);
   if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_scene, 1);
+  if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_tri_pos, (size_t)sd->n_tris * 9);
+  if (rc == RRT_OK) rc = dev_alloc(ctx, &ctx->d_exact, 1);
   if (rc == RRT_OK && st.has_env) rc = dev_alloc(ctx, &ctx->d_env, (size_t)sd->env_w * sd->env_h * 4);
   if (rc != RRT_OK) { free_bvh(&bvh); free_scene(ctx); return rc; }
   hipError_t e = hipSuccess;
@@ -863,6 +915,24 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   if (!device_build && e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tri_shade, shade, sizeof(TriShade) * (size_t)sd->n_tris, hipMemcpyHostToDevice);
   if (e == hipSuccess && sd->n_materials) e = hipMemcpy(ctx->d_materials, mats.data(), sizeof(DeviceMaterial) * mats.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(ctx->d_scene, &st, sizeof(st), hipMemcpyHostToDevice);
+  if (e == hipSuccess && sd->n_tris) e = hipMemcpy(ctx->d_tri_pos, sd->tri_pos, sizeof(float) * 9 * (size_t)sd->n_tris, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    ShapesF64 ex;
+    std::memset(&ex, 0, sizeof(ex));
+    for (uint32_t i = 0; i < sd->n_rects; ++i) {
+      double n[3];
+      cross3(sd->rects[i].side_a, sd->rects[i].side_b, n);
+      const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      for (int k = 0; k < 3; ++k) { ex.rect_pos[i][k] = sd->rects[i].pos[k]; ex.rect_normal[i][k] = n[k] / l; }
+    }
+    for (uint32_t i = 0; i < sd->n_planes; ++i)
+      for (int k = 0; k < 3; ++k) { ex.plane_pos[i][k] = sd->planes[i].pos[k]; ex.plane_normal[i][k] = sd->planes[i].normal[k]; }
+    for (uint32_t i = 0; i < sd->n_spheres; ++i) {
+      for (int k = 0; k < 3; ++k) ex.sphere_center[i][k] = sd->spheres[i].center[k];
+      ex.sphere_radius[i] = sd->spheres[i].radius;
+    }
+    e = hipMemcpy(ctx->d_exact, &ex, sizeof(ex), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess && st.has_env) {
     // one 4-byte texel per lookup instead of three byte loads
     std::vector<uint8_t> rgba((size_t)sd->env_w * sd->env_h * 4);
@@ -1201,7 +1271,7 @@ int rrt_render(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint3
   try {
     return render_impl(ctx, s, sample_begin, sample_end);
   } catch (...) {  // std::bad_alloc (the list of state allocations, the timing events, an error string)
-    return RRT_E_NOMEM;
+    return fail_static(ctx, RRT_E_NOMEM, "rrt_render: out of host memory");
   }
 }
 
@@ -1232,7 +1302,7 @@ int rrt_intersect(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_t* prim_
     if (e == hipSuccess) {
       e = hipMemsetAsync(ctx->d_work, 0, sizeof(uint32_t), ctx->stream);
       hipLaunchKernelGGL(k_intersect, dim3(std::min(grid_for(n), kTraceGridBlocks)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes,
-                         ctx->d_tris, ctx->d_scene, d_rays, n, d_prim, d_t, ctx->d_work);
+                         ctx->d_tris, ctx->d_tri_pos, ctx->d_exact, ctx->d_scene, d_rays, n, d_prim, d_t, ctx->d_work);
       if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(prim_id, d_prim, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
@@ -1268,7 +1338,7 @@ int rrt_intersect_noalloc(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_
   HIP_TRY(ctx, hipMemsetAsync(d_cursor, 0, kScratchCursorBytes, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_rays, org_dir, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_intersect, dim3(std::min(grid_for(n), kTraceGridBlocks)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes,
-                     ctx->d_tris, ctx->d_scene, d_rays, n, d_prim, d_t, d_cursor);
+                     ctx->d_tris, ctx->d_tri_pos, ctx->d_exact, ctx->d_scene, d_rays, n, d_prim, d_t, d_cursor);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(prim_id, d_prim, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(t, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1349,6 +1419,7 @@ int rrt_get_stats(rrt_ctx* ctx, rrt_stats* out) {
   for (int k = 0; k < 3; ++k) {
     out->nodes_by_kernel[k] = ds.nodes[k];
     out->tris_by_kernel[k] = ds.tris[k];
+    out->rays_entered_by_kernel[k] = ds.entered[k];
     out->nodes_visited += ds.nodes[k];
     out->tris_tested += ds.tris[k];
   }
@@ -1388,6 +1459,7 @@ int rrt_get_stats(rrt_ctx* ctx, rrt_stats* out) {
 
 int64_t rrt_bvh_selfcheck(const float* tri_pos, uint32_t n_tris, uint32_t* n_nodes, uint32_t* max_depth) {
   if (!tri_pos && n_tris) return RRT_E_INVALID;
+  thread_switch_from_environment();
   BvhBuildResult bvh;
   if (!build_bvh(tri_pos, n_tris, 0, &bvh)) return RRT_E_NOMEM;
   if (n_nodes) *n_nodes = bvh.n_nodes;
@@ -1500,7 +1572,6 @@ struct CommSet {
   std::vector<int> devices;
   std::vector<comm_t> comms;
 };
-std::atomic<bool> g_reduce_single_through_rccl{false};  // test hook, see rrt_debug_reduce_single_through_rccl
 std::mutex g_comm_mutex;           // also serialises reduces: a communicator runs one collective at a time
 std::vector<CommSet> g_comm_sets;
 void destroy_comm_sets() {
@@ -1552,7 +1623,8 @@ int film_reduce_impl(rrt_ctx** ctxs, int n, int root) {
     if (api.reduce(ctxs[i]->d_film, ctxs[i]->d_film, count, kFloat32, kSum, root, set->comms[i], ctxs[i]->stream) != 0) rc = RRT_E_DEVICE;
   }
   if (api.group_end() != 0) rc = RRT_E_DEVICE;
-  // the first-hit buffers as well, when every context keeps them
+  // the first-hit buffers as well, when every context keeps them (not after a failure: the communicators are
+  // in an unknown state then)
   bool all_aovs = true;
   for (int i = 0; i < n; ++i)
     all_aovs = all_aovs && ctxs[i]->aovs && ctxs[i]->d_aov && ctxs[i]->aov_w == ctxs[0]->film_w && ctxs[i]->aov_h == ctxs[0]->film_h;
@@ -1564,11 +1636,22 @@ int film_reduce_impl(rrt_ctx** ctxs, int n, int root) {
     }
     if (api.group_end() != 0) rc = RRT_E_DEVICE;
   }
-  for (int i = 0; i < n; ++i) {
-    (void)hipSetDevice(ctxs[i]->device);
-    if (hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) rc = RRT_E_DEVICE;
+  if (rc == RRT_OK)
+    for (int i = 0; i < n; ++i) {
+      (void)hipSetDevice(ctxs[i]->device);
+      if (hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) rc = RRT_E_DEVICE;
+    }
+  if (rc != RRT_OK) {
+    // A communicator that has seen a failed or half-enqueued collective is not used again: the set goes, and
+    // the next reduce over these devices makes a fresh one.  (No wait on the streams: a rank that was only
+    // partly enqueued would never finish.)
+    for (size_t i = 0; i < set->comms.size(); ++i) {
+      (void)hipSetDevice(set->devices[i]);
+      if (set->comms[i]) api.comm_destroy(set->comms[i]);
+    }
+    g_comm_sets.erase(g_comm_sets.begin() + (set - g_comm_sets.data()));
+    return fail(ctxs[root], rc, "ncclReduce failed");
   }
-  if (rc != RRT_OK) return fail(ctxs[root], rc, "ncclReduce failed");
   return RRT_OK;
 }
 }  // namespace
@@ -1581,23 +1664,16 @@ int rrt_film_reduce(rrt_ctx** ctxs, int n, int root) {
   for (int i = 1; i < n; ++i)
     if (ctxs[i]->film_w != ctxs[0]->film_w || ctxs[i]->film_h != ctxs[0]->film_h)
       return fail(ctxs[i], RRT_E_INVALID, "films differ in size");
-  if (n == 1 && !g_reduce_single_through_rccl.load()) return RRT_OK;
+  // One context: nothing to add.  (A context created with RRT_DEBUG_REDUCE_SINGLE_THROUGH_RCCL in the environment
+  // sends even that through a one-rank communicator -- the film comes back unchanged -- so that a machine with one
+  // GPU can run the library loading, the communicator cache and the collective.)
+  if (n == 1 && !ctxs[0]->debug_reduce_through_rccl) return RRT_OK;
   try {
     return film_reduce_impl(ctxs, n, root);
   } catch (...) {
-    return RRT_E_NOMEM;
+    return fail_static(ctxs[root], RRT_E_NOMEM, "rrt_film_reduce: out of host memory");
   }
 }
-
-// Test hook, not part of include/rrt.h: a reduce over a single context normally returns at once; with
-// this on it goes through RCCL like any other (a one-rank communicator: the film comes back unchanged),
-// which lets a machine with one GPU run the library loading, the communicator cache and the collective.
-void rrt_debug_reduce_single_through_rccl(int on) { g_reduce_single_through_rccl.store(on != 0); }
-
-// Test hook, not part of include/rrt.h: after `n` more host threads every further thread creation of
-// the library is refused as if the system had none left (n < 0: back to normal).  The library must
-// then do the refused thread's work on the thread that asked, with the same result.
-void rrt_debug_fail_threads_after(int n) { g_thread_creations_allowed.store(n < 0 ? -1 : n); }
 
 const char* rrt_last_error(rrt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 

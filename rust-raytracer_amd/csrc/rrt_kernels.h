@@ -65,6 +65,7 @@ namespace rrt {
 struct DeviceStats {
   unsigned long long paths, rays_extend, rays_shadow, path_bounces, rays_primary;
   unsigned long long nodes[3], tris[3];  // per traversal kernel: primary, extend, connect
+  unsigned long long entered[3];         // rays that went into the hierarchy, likewise
 };
 
 // Flags kept in the w lane of the shadow-contribution record.
@@ -284,6 +285,7 @@ RRT_DEV void flush_counters(DeviceStats* stats, int kernel, const TraceCounters&
   if (COUNT) {
     atomicAdd(&stats->nodes[kernel], (unsigned long long)ctr.nodes);
     atomicAdd(&stats->tris[kernel], (unsigned long long)ctr.tris);
+    atomicAdd(&stats->entered[kernel], (unsigned long long)ctr.entered);
   }
 }
 
@@ -515,7 +517,7 @@ __global__ void __launch_bounds__(kTraceBlock, RRT_EXTEND_WAVES) k_extend(Render
   const uint32_t longest_s = queue_lengths(p, kRowCamera, lens_s);
   const uint32_t grab = grab_size(longest_c + longest_s, gridDim.x * (kTraceBlock / 64));
   const uint32_t blocks_c = queue_blocks(longest_c, grab);
-  TraceCounters ctr = {0, 0};
+  TraceCounters ctr = {0, 0, 0};
   ExtendJob<COUNT> job = {p, sc, lens_c, lens_s, blocks_c, grab, parity, nullptr, 0, 0, false, 0, false, false};
   trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
                              blocks_c + queue_blocks(longest_s, grab), RRT_REFILL_QUORUM, job, &ctr, rrt_trace_stack);
@@ -611,7 +613,7 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_primary(RenderParams p, Came
   RRT_DECLARE_SHAPES();
   const SceneTables* sc = shapes_to_lds(p.scene, rrt_shape_words);
   const uint32_t grab = grab_size((p.n_slots + kSegments - 1) / kSegments, gridDim.x * (kTraceBlock / 64));
-  TraceCounters ctr = {0, 0};
+  TraceCounters ctr = {0, 0, 0};
   PrimaryJob<COUNT> job = {p, cam, sc, grab, p.single != 0, 0, 0, 0, 0, 0, false};
   trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
                              (p.n_slots + grab - 1) / grab, RRT_REFILL_QUORUM_COHERENT, job, &ctr, rrt_trace_stack);
@@ -885,7 +887,7 @@ __global__ void RRT_TRACE_BOUNDS k_connect(RenderParams p) {
   __shared__ uint32_t lens[kSegments + 1];
   const uint32_t longest = queue_lengths(p, kRowShadow, lens);
   const uint32_t grab = grab_size(longest, gridDim.x * (kTraceBlock / 64));
-  TraceCounters ctr = {0, 0};
+  TraceCounters ctr = {0, 0, 0};
   ConnectJob job = {p, sc, lens, grab, nullptr, 0, 0, 0, -1, -1, 0.0f, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
   trace_stream<true, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkConnect, 0),
                             queue_blocks(longest, grab), RRT_REFILL_QUORUM, job, &ctr, rrt_trace_stack);
@@ -1093,7 +1095,7 @@ __global__ void RRT_TAIL_BOUNDS k_tail(RenderParams p, uint32_t parity) {
   const uint32_t longest = queue_lengths(p, row_cont(parity), lens);
   // small blocks: the jobs are long and few, and every wave should get some
   const uint32_t grab = 64;
-  TraceCounters ctr = {0, 0};
+  TraceCounters ctr = {0, 0, 0};
   TailJob<COUNT> job = {p, sc, lens, grab, parity};
   trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
                              queue_blocks(longest, grab), RRT_TAIL_QUORUM, job, &ctr, rrt_trace_stack);
@@ -1187,6 +1189,8 @@ struct IntersectJob {
   static constexpr int kDebugRow = 0;  // row of the diagnostic build's counters
   static constexpr bool kRootTest = true;  // its rays may start anywhere
   const TriIsect* tris;
+  const float* tri_pos;     // scene order, [n_tris][3][3]: the vertices as uploaded
+  const ShapesF64* exact;   // the analytic shapes' parameters in f64
   const SceneTables* sc;
   const float* org_dir;
   int32_t* prim_id;
@@ -1211,23 +1215,41 @@ struct IntersectJob {
     Hit h = tri_hit;
     if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
     int id = h.prim;
-    if (id >= 0 && id < sc->n_tris) id = __float_as_int(tris[id].v0.w);  // leaf order -> scene order
+    float t = h.prim >= 0 ? h.t : 0.0f;
+    if (id >= 0) {
+      // which object: decided above, in f32.  How far: that one object once more, in f64 (exact_*_t).
+      double te = -1.0;
+      int k = id - sc->n_tris;
+      if (k < 0) {
+        id = __float_as_int(tris[id].v0.w);  // leaf order -> scene order
+        te = exact_triangle_t(tri_pos + (size_t)id * 9, r.o, r.d);
+      } else if (k < sc->n_rects) {
+        te = exact_plane_t(exact->rect_pos[k], exact->rect_normal[k], r.o, r.d, 1e-9);
+      } else if ((k -= sc->n_rects) < sc->n_planes) {
+        te = exact_plane_t(exact->plane_pos[k], exact->plane_normal[k], r.o, r.d, 1e-7);
+      } else {
+        k -= sc->n_planes;
+        te = exact_sphere_t(exact->sphere_center[k], exact->sphere_radius[k], r.o, r.d);
+      }
+      if (te > 0.0) t = (float)te;
+    }
     prim_id[index] = id;
-    t_out[index] = h.prim >= 0 ? h.t : 0.0f;
+    t_out[index] = t;
     return false;
   }
   RRT_DEV void retire() {}
   RRT_DEV void flush(bool, uint32_t) {}
 };
 
-__global__ void RRT_TRACE_BOUNDS k_intersect(const BvhNode* nodes, const TriIsect* tris,
-                                                           const SceneTables* sc, const float* __restrict__ org_dir,
-                                                           uint32_t n, int32_t* prim_id, float* t_out, uint32_t* work_cursor) {
+__global__ void RRT_TRACE_BOUNDS k_intersect(const BvhNode* nodes, const TriIsect* tris, const float* __restrict__ tri_pos,
+                                             const ShapesF64* __restrict__ exact, const SceneTables* sc,
+                                             const float* __restrict__ org_dir, uint32_t n, int32_t* prim_id, float* t_out,
+                                             uint32_t* work_cursor) {
   RRT_DECLARE_TRACE_STACK();
   RRT_DECLARE_SHAPES();
   sc = shapes_to_lds(sc, rrt_shape_words);
-  TraceCounters ctr = {0, 0};
-  IntersectJob job = {tris, sc, org_dir, prim_id, t_out, n, 0, 0};
+  TraceCounters ctr = {0, 0, 0};
+  IntersectJob job = {tris, tri_pos, exact, sc, org_dir, prim_id, t_out, n, 0, 0};
   trace_stream<false, false>(nodes, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, RRT_REFILL_QUORUM, job, &ctr,
                              rrt_trace_stack);
 }
@@ -1275,7 +1297,7 @@ __global__ void RRT_TRACE_BOUNDS k_occluded(const BvhNode* nodes, const TriIsect
   RRT_DECLARE_TRACE_STACK();
   RRT_DECLARE_SHAPES();
   sc = shapes_to_lds(sc, rrt_shape_words);
-  TraceCounters ctr = {0, 0};
+  TraceCounters ctr = {0, 0, 0};
   OccludedJob job = {sc, odt, out, n, 0, 0, 0.0f};
   trace_stream<true, false>(nodes, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, RRT_REFILL_QUORUM, job, &ctr,
                             rrt_trace_stack);

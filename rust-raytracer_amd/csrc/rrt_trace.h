@@ -119,6 +119,7 @@ RRT_DEV bool intersect_tri(const TriRec& rec, const RayPre& r, float tmin, float
 
 struct TraceCounters {
   uint32_t nodes, tris;
+  uint32_t entered;  // rays that passed the root-box test (all rays of a job type without that test)
 };
 
 #ifdef RRT_PHASE_CLOCKS
@@ -332,6 +333,7 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
       const float tf_ = fminf(fminf(fmaxf(ax_, bx_), fmaxf(ay_, by_)), fminf(fmaxf(az_, bz_), tmax));   \
       enter_ = tn_ <= tf_ * 1.0000005f;                      \
     }                                                        \
+    if (COUNT && enter_) ctr->entered++;                     \
     state = enter_ ? kTravelling : kArrived;                 \
   } while (0)
   // entries pushed before the ray found its current hit may lie beyond it: those are skipped unread
@@ -639,6 +641,69 @@ RRT_DEV bool intersect_sphere(const DeviceSphere& s, const RayPre& r, float* t_o
   }
   *t_out = t;
   return true;
+}
+
+// ---------------------------------------------------------------- exact distances for the first-hit hook
+// rrt_intersect reports distances to 1e-5 relative.  The f32 traversal decides WHICH object a ray hits;
+// its t, from edges already rounded to f32 and a hardware reciprocal, is short of that on short rays
+// (a few 1e-3 relative at t ~ 1e-3 of the scene).  The hook therefore re-evaluates the one object
+// that won, once, in f64, from the data the reference itself computes from: the f32 vertices as
+// uploaded (objects/triangle.rs:59-107 widens them to f64) and the f64 shape parameters.
+struct ShapesF64 {
+  double rect_pos[RRT_MAX_RECTS][3], rect_normal[RRT_MAX_RECTS][3];  // normal = normalize(a x b), rectangle.rs:44-46
+  double plane_pos[RRT_MAX_PLANES][3], plane_normal[RRT_MAX_PLANES][3];
+  double sphere_center[RRT_MAX_SPHERES][3], sphere_radius[RRT_MAX_SPHERES];
+};
+
+// Distance to a triangle by the reference's own test (objects/triangle.rs:119-181: translate to the
+// ray origin, permute so that the direction's largest component is z, shear, edge functions) in f64.
+// Returns a negative value when that test rejects the ray (the caller then keeps the f32 distance:
+// such a ray is on an edge, where the two arithmetics may disagree about hit or miss).
+RRT_DEV double exact_triangle_t(const float* __restrict__ p, V3 of, V3 df) {
+  const double o[3] = {(double)of.x, (double)of.y, (double)of.z}, d[3] = {(double)df.x, (double)df.y, (double)df.z};
+  int kz = 0;
+  if (fabs(d[1]) > fabs(d[kz])) kz = 1;
+  if (fabs(d[2]) > fabs(d[kz])) kz = 2;
+  const int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+  const double sx = -d[kx] / d[kz], sy = -d[ky] / d[kz], sz = 1.0 / d[kz];
+  double x[3], y[3], z[3];
+  for (int v = 0; v < 3; ++v) {
+    const double tx = (double)p[3 * v + kx] - o[kx], ty = (double)p[3 * v + ky] - o[ky], tz = (double)p[3 * v + kz] - o[kz];
+    x[v] = tx + sx * tz;
+    y[v] = ty + sy * tz;
+    z[v] = tz * sz;
+  }
+  const double e0 = x[1] * y[2] - y[1] * x[2], e1 = x[2] * y[0] - y[2] * x[0], e2 = x[0] * y[1] - y[0] * x[1];
+  if ((e0 < 0.0 || e1 < 0.0 || e2 < 0.0) && (e0 > 0.0 || e1 > 0.0 || e2 > 0.0)) return -1.0;
+  const double det = e0 + e1 + e2;
+  if (det == 0.0) return -1.0;
+  const double t_scaled = e0 * z[0] + e1 * z[1] + e2 * z[2];
+  if (det < 0.0 && (t_scaled >= 0.0 || t_scaled < 1000.0 * det)) return -1.0;
+  if (det > 0.0 && (t_scaled <= 0.0 || t_scaled > 1000.0 * det)) return -1.0;
+  const double t = t_scaled * (1.0 / det);
+  return t < 2.220446049250313e-16 ? -1.0 : t;
+}
+
+// Distance to the analytic shape `k` of its kind (objects/rectangle.rs:58-71, plane.rs:45-57,
+// sphere.rs:116-151) in f64; negative: rejected, keep the f32 distance.
+RRT_DEV double exact_plane_t(const double* pos, const double* n, V3 of, V3 df, double t_least) {
+  const double denom = n[0] * (double)df.x + n[1] * (double)df.y + n[2] * (double)df.z;
+  if (fabs(denom) < 1e-9) return -1.0;
+  const double t = ((pos[0] - (double)of.x) * n[0] + (pos[1] - (double)of.y) * n[1] + (pos[2] - (double)of.z) * n[2]) / denom;
+  return t < t_least ? -1.0 : t;
+}
+RRT_DEV double exact_sphere_t(const double* c, double radius, V3 of, V3 df) {
+  const double oc[3] = {(double)of.x - c[0], (double)of.y - c[1], (double)of.z - c[2]};
+  const double d[3] = {(double)df.x, (double)df.y, (double)df.z};
+  const double a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
+  const double cc = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - radius * radius;
+  const double disc = b * b - a * cc;
+  if (disc < 0.0) return -1.0;
+  const double sq = sqrt(disc);
+  double t = (-b - sq) / a;
+  if (t > 0.0001) return t;
+  t = (-b + sq) / a;
+  return t > 0.0001 ? t : -1.0;
 }
 
 // Analytic shapes after the triangles: closest hit below hit->t (or any below tmax).

@@ -33,7 +33,23 @@ def test_sample_ranges_partition():
         d.sample_range(2, 2, 10)
 
 
-def _worker(rank, world, port, mode, out_path):
+def test_strong_scaling_ranges_of_the_4k_configuration_cover_every_sample_once():
+    """bench.py --scaling strong --spp 4096: the ranks' sample ranges are disjoint, in rank order, and their union
+    is exactly [0, 4096) -- for the 2, 4 and 8 GPUs of the configuration and for counts that do not divide 4096."""
+    d = _load_distributed()
+    for world in (2, 3, 4, 5, 7, 8):
+        seen = np.zeros(4096, dtype=np.int32)
+        for r in range(world):
+            b, e = d.sample_range(r, world, 4096)
+            seen[b:e] += 1
+            assert e - b in (4096 // world, 4096 // world + 1)
+        assert (seen == 1).all(), world
+    # and bench.py takes its ranges from there
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "rrdist.sample_range(rank, world, SPP)" in src and "rrdist.weak_sample_range(rank, SPP)" in src
+
+
+def _worker(rank, world, port, mode, out_path, size=(24, 24, 6)):
     import torch
     import torch.distributed as dist
 
@@ -49,7 +65,7 @@ def _worker(rank, world, port, mode, out_path):
     folder = os.path.join(rr.SCENES, "cornell")
     scene = rr.Scene.load_from_folder(folder)
     rs = rr.load_render_settings(folder)
-    w, h, spp = 24, 24, 6
+    w, h, spp = size
     orc = ob.Oracle(scene.desc())
     orc.set_camera(rr.Camera.from_settings(rs, w, h))
     s = rr.make_settings(w, h, 4, rs.clamp, seed=12)
@@ -81,3 +97,25 @@ def test_two_rank_render_equals_one(rrt, oracle_binding, cornell, tmp_path, mode
     ref, _ = orc.render(s, 0, total, threads=2)
     assert (got[..., 3] == total).all()
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_strong_split_of_4096_samples_equals_one_rank(rrt, oracle_binding, cornell, tmp_path, world):
+    """The sample-sharded configuration's arithmetic at its full sample count on a small frame: 4096 samples per
+    pixel split over 2 ranks, and over 3 (4096 / 3 does not divide: 1365 + 1365 + 1366), rendered by the ranks,
+    summed onto rank 0 -- against one rank rendering [0, 4096).  Every pixel gets every sample exactly once."""
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    out = str(tmp_path / "film.npy")
+    w, h, spp = 6, 6, 4096
+    mp.spawn(_worker, args=(world, port, "strong", out, (w, h, spp)), nprocs=world, join=True)
+    got = np.load(out)
+    scene, rs = cornell
+    orc = oracle_binding.Oracle(scene.desc())
+    orc.set_camera(rrt.Camera.from_settings(rs, w, h))
+    ref, _ = orc.render(rrt.make_settings(w, h, 4, rs.clamp, seed=12), 0, spp, threads=4)
+    assert (got[..., 3] == spp).all()
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-5)

@@ -1,0 +1,202 @@
+"""The reference's own known-answer tests, sent through the HIP path (C ABI -> kernels).
+
+tests/test_oracle_kat.py pins the CPU oracle to the reference's 25 inline #[test]s.  The ones that
+state something a kernel computes are repeated here against the device, so that the reference's own
+vectors pin the product and not only its checker:
+
+* src/objects/triangle.rs:379-426   the triangle vector through rrt_intersect (id, t == 2.0 exactly) and its
+                                    shading normal through a render's first-hit buffer;
+* src/camera.rs:166-259             the camera vector through k_primary: a 100 x 100 film, fov 90, in front of a
+                                    target whose every cell has its own albedo -- which cell each pixel's camera rays
+                                    hit says where the device's rays go (centre ray, 90 degrees edge to edge, the
+                                    re-targeted camera);
+* src/bsdf/helpers/fresnel.rs:76-154 and src/bsdf/specular_reflection.rs:44-151
+                                    FresnelDielectric(1, 1.5) at normal incidence (0.04), at cos 0.5 (0.08918), total
+                                    internal reflection from inside (1), FresnelNoop (1): a specular surface under a
+                                    distant light of intensity I, whose every path carries F * R * I or nothing.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _triangle_scene(rrt):
+    pos = np.array([[[-1.0, -1.0, 0.0], [1.0, -1.0, 0.0], [1.0, 1.0, 0.0]]], dtype=np.float32)
+    nrm = np.array([[[0.6, 0.0, -1.0], [0.0, 0.5, -1.0], [0.4, 0.0, -1.0]]], dtype=np.float32)
+    return rrt.SceneArrays(pos, nrm, [0], materials=[rrt.make_material(rrt.MAT_MATTE, kd=(0.5, 0.5, 0.5))])
+
+
+def test_triangle_vector_first_hit(rrt, gpu_ctx):
+    """src/objects/triangle.rs:379-426: the ray from (0, 0, -2) along +z meets the triangle on its hypotenuse
+    (barycentric u = -0.0), at distance exactly 2."""
+    gpu_ctx.upload_scene(_triangle_scene(rrt))
+    for call in (gpu_ctx.intersect, gpu_ctx.intersect_noalloc):
+        prim, t = call(np.array([[0.0, 0.0, -2.0, 0.0, 0.0, 1.0]], dtype=np.float32))
+        assert prim[0] == 0
+        assert t[0] == 2.0
+    # the same triangle from the other side, from inside its outline, and past it
+    prim, t = gpu_ctx.intersect(np.array([[0.5, -0.5, 3.0, 0.0, 0.0, -1.0],
+                                          [0.5, -0.5, -0.25, 0.0, 0.0, 1.0],
+                                          [-0.5, 0.5, -2.0, 0.0, 0.0, 1.0],
+                                          [0.5, -0.5, -2.0, 0.0, 0.0, -1.0]], dtype=np.float32))
+    assert list(prim) == [0, 0, -1, -1]
+    assert t[0] == 3.0 and t[1] == 0.25
+
+
+def test_triangle_vector_shading_normal(rrt, gpu_ctx):
+    """Same vector: the shading normal at that point is normalize(0.5, 0, -1) (blend of the vertex normals).
+    Seen through a render: a camera at (0, 0, -2) looking along +z through a 0.001-degree field of view, so that
+    every camera ray is the vector's ray to within 2e-8; the first-hit buffer holds the shading normals of those that hit."""
+    gpu_ctx.upload_scene(_triangle_scene(rrt))
+    w = h = 8
+    cam = rrt.Camera((0.0, 0.0, -2.0), (0.0, 0.0, 0.0), 1e-3, 0.0, None, w, h)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    gpu_ctx.set_option(rrt.OPT_AOVS, 1)
+    try:
+        gpu_ctx.film_clear()
+        gpu_ctx.render(rrt.make_settings(w, h, 1, 10.0, seed=1), 0, 4)
+        normal, _ = gpu_ctx.aov_download()
+    finally:
+        gpu_ctx.set_option(rrt.OPT_AOVS, 0)
+    # the vector's ray runs through the triangle's hypotenuse: the camera rays on one side of it hit, the others miss
+    hits = normal[..., 3]
+    assert 0.3 * 4 * w * h <= hits.sum() <= 0.7 * 4 * w * h
+    ns = normal[hits > 0, :3] / hits[hits > 0, None]
+    expected = np.array([0.5, 0.0, -1.0]) / np.linalg.norm([0.5, 0.0, -1.0])
+    np.testing.assert_allclose(ns, np.tile(expected, (len(ns), 1)), rtol=1e-6, atol=1e-6)
+
+
+def _camera_target(rrt, position, target, cells=100):
+    """A square of cells x cells quads with an albedo each, filling exactly the field of view of a fov-90 camera
+    at `position` looking at `target`, one unit in front of it.  Cell (i, j) lies at camera-space x in
+    [2 i / cells - 1, 2 (i + 1) / cells - 1), y likewise with j counted upwards; the camera's x axis is
+    up x view, its y axis view x (x axis) (src/camera.rs:54-62, nalgebra's face_towards)."""
+    p, t = np.asarray(position, dtype=np.float64), np.asarray(target, dtype=np.float64)
+    view = (t - p) / np.linalg.norm(t - p)
+    x_axis = np.cross([0.0, 1.0, 0.0], view)
+    x_axis /= np.linalg.norm(x_axis)
+    y_axis = np.cross(view, x_axis)
+    centre = p + view
+    i, j = np.meshgrid(np.arange(cells), np.arange(cells), indexing="xy")
+    i, j = i.ravel(), j.ravel()
+    x0, x1 = 2.0 * i / cells - 1.0, 2.0 * (i + 1) / cells - 1.0
+    y0, y1 = 2.0 * j / cells - 1.0, 2.0 * (j + 1) / cells - 1.0
+
+    def corner(x, y):
+        return centre + x[:, None] * x_axis + y[:, None] * y_axis
+    a, b, c, d = corner(x0, y0), corner(x1, y0), corner(x1, y1), corner(x0, y1)
+    pos = np.concatenate([np.stack([a, b, c], axis=1), np.stack([a, c, d], axis=1)]).astype(np.float32)
+    nrm = np.broadcast_to(-view, pos.shape).astype(np.float32)
+    mat = np.concatenate([np.arange(cells * cells)] * 2)
+    materials = [rrt.make_material(rrt.MAT_MATTE, kd=((ii + 0.5) / cells, (jj + 0.5) / cells, 0.5)) for ii, jj in zip(i, j)]
+    return rrt.SceneArrays(pos, nrm, mat, materials=materials)
+
+
+@pytest.mark.parametrize("target", [(0.0, 0.0, 0.0), (0.0, 1.0, 0.0)])
+def test_camera_vector_through_primary_kernel(rrt, gpu_ctx, target):
+    """src/camera.rs:166-259: 100 x 100 film, fov 90, camera at (0, 0, 1).  Looking at the origin the ray through
+    film position (50, 50) is (0, 0, -1) and the rays through x = 0 and x = 100 are 90 degrees apart; looking at
+    (0, 1, 0) the centre ray is normalize(0, 1, -1).  For the device's camera rays that means: the samples of pixel
+    (px, py) -- film x in [px, px + 1) -- all land in cell (px, 99 - py) of a target that fills a 90-degree field
+    of view one unit in front of the camera (film x = 50 is the target's centre line, x = 0 and x = 100 its edges)."""
+    w = h = cells = 100
+    position = (0.0, 0.0, 1.0)
+    gpu_ctx.upload_scene(_camera_target(rrt, position, target, cells))
+    cam = rrt.Camera(position, target, 90.0, 0.0, None, w, h)
+    # the host camera states the vector itself (tests/test_oracle_kat.py checks it on the CPU as well)
+    view = np.asarray(target) - np.asarray(position)
+    np.testing.assert_allclose(cam.generate_ray(50.0, 50.0)[1], view / np.linalg.norm(view), atol=1e-12)
+    left, right = cam.generate_ray(0.0, 50.0)[1], cam.generate_ray(100.0, 50.0)[1]
+    assert np.degrees(np.arccos(np.dot(left, right))) == pytest.approx(90.0, rel=1e-5)
+    gpu_ctx.set_camera(cam)
+    gpu_ctx.film_alloc(w, h)
+    gpu_ctx.set_option(rrt.OPT_AOVS, 1)
+    spp = 4
+    try:
+        gpu_ctx.film_clear()
+        gpu_ctx.render(rrt.make_settings(w, h, 1, 10.0, seed=7), 0, spp)
+        normal, albedo = gpu_ctx.aov_download()
+    finally:
+        gpu_ctx.set_option(rrt.OPT_AOVS, 0)
+    hits = normal[..., 3]
+    # a sample on the film's outermost column or row may round past the target's edge
+    assert (hits[1:-1, 1:-1] == spp).all() and hits.sum() >= spp * (w * h - 8)
+    px, py = np.meshgrid(np.arange(w), np.arange(h), indexing="xy")
+    expected = np.stack([(px + 0.5) / cells, ((h - 1 - py) + 0.5) / cells, np.full(px.shape, 0.5)], axis=-1)
+    seen = albedo[..., :3] / np.maximum(hits, 1.0)[..., None]
+    off = (np.abs(seen - expected).max(axis=-1) > 1e-5) & (hits > 0)
+    # (a film position within an f32 ulp of a pixel's border may land in the neighbouring cell)
+    assert off.sum() <= 3, np.argwhere(off)[:10]
+
+
+def _specular_radiances(rrt, ctx, scene, cam, w, h, seed):
+    """Per-sample radiance of a 1-sample-per-pixel render (red channel), after checking the three channels agree."""
+    ctx.upload_scene(scene)
+    ctx.set_camera(cam)
+    ctx.film_alloc(w, h)
+    ctx.film_clear()
+    ctx.render(rrt.make_settings(w, h, 4, 0.0, seed=seed), 0, 1)
+    film = ctx.film_download()
+    assert (film[..., 3] == 1.0).all()
+    np.testing.assert_array_equal(film[..., 0], film[..., 1])
+    np.testing.assert_array_equal(film[..., 0], film[..., 2])
+    return film[..., 0].ravel().astype(np.float64)
+
+
+INTENSITY = 2.0
+
+
+def _distant(rrt):
+    # (its direction does not matter: a specular surface takes nothing from the light sample, and every ray that
+    # leaves the scene after a specular bounce collects the light's intensity, src/lights/distant.rs:62-64)
+    return [rrt.make_light(rrt.LIGHT_DISTANT, intensity=(INTENSITY,) * 3, v0=(0.3, 1.0, 0.2))]
+
+
+def test_fresnel_vectors_normal_incidence(rrt, gpu_ctx):
+    """src/bsdf/helpers/fresnel.rs: FresnelDielectric(1, 1.5).evaluate(1.0) = 0.04.  A glass sphere (reflectance 1,
+    transmittance 0) seen head-on: a path that draws the reflection lobe carries F * I, one that draws the
+    (black) transmission lobe ends with nothing; the lobe is drawn uniformly (src/bsdf.rs:133)."""
+    w = h = 64
+    glass = rrt.make_material(rrt.MAT_GLASS, kd=(1.0, 1.0, 1.0), ks=(0.0, 0.0, 0.0), ior=1.5)
+    scene = rrt.SceneArrays(materials=[glass], lights=_distant(rrt), spheres=[rrt.make_sphere((0.0, 0.0, 0.0), 1.0, 0)])
+    cam = rrt.Camera((3.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.02, 0.0, None, w, h)
+    l = _specular_radiances(rrt, gpu_ctx, scene, cam, w, h, seed=3)
+    lit = l > 0
+    assert 0.42 < lit.mean() < 0.58
+    np.testing.assert_allclose(l[lit] / INTENSITY, 0.04, atol=1e-4)
+
+
+def test_fresnel_vectors_oblique_and_total_internal_reflection(rrt, gpu_ctx):
+    """evaluate(0.5) = 0.08918 (1e-3) from outside; FresnelDielectric(1.5, 1.0).evaluate(0.5) = 1: seen from inside
+    (cos < 0 swaps the indices) at 60 degrees everything is reflected.  A horizontal glass plane seen at 60 degrees
+    of incidence from above, then from below."""
+    w = h = 64
+    glass = rrt.make_material(rrt.MAT_GLASS, kd=(1.0, 1.0, 1.0), ks=(0.0, 0.0, 0.0), ior=1.5)
+    scene = rrt.SceneArrays(materials=[glass], lights=_distant(rrt), planes=[rrt.make_plane((0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0)])
+    s60, c60 = np.sin(np.radians(60.0)), 0.5
+    for side, expect, tol in ((+1.0, 0.08918, 1e-3), (-1.0, 1.0, 1e-4)):
+        cam = rrt.Camera((-2.0 * s60, side * 2.0 * c60, 0.0), (0.0, 0.0, 0.0), 0.02, 0.0, None, w, h)
+        l = _specular_radiances(rrt, gpu_ctx, scene, cam, w, h, seed=5)
+        lit = l > 0
+        assert 0.42 < lit.mean() < 0.58, (side, lit.mean())
+        np.testing.assert_allclose(l[lit] / INTENSITY, expect, atol=tol)
+    # the exact value behind the reference's 0.08918: unpolarised Fresnel at cos 0.5, n = 1.5
+    ct = np.sqrt(1.0 - (s60 / 1.5) ** 2)
+    exact = 0.5 * (((1.5 * c60 - ct) / (1.5 * c60 + ct)) ** 2 + ((c60 - 1.5 * ct) / (c60 + 1.5 * ct)) ** 2)
+    cam = rrt.Camera((-2.0 * s60, 2.0 * c60, 0.0), (0.0, 0.0, 0.0), 0.02, 0.0, None, w, h)
+    l = _specular_radiances(rrt, gpu_ctx, scene, cam, w, h, seed=6)
+    np.testing.assert_allclose(l[l > 0] / INTENSITY, exact, rtol=2e-3)  # (the field of view spans 0.02 degrees of incidence)
+
+
+def test_fresnel_noop_mirror(rrt, gpu_ctx):
+    """src/bsdf/specular_reflection.rs:44-151 with FresnelNoop: f * |cos| = R at any angle -- a mirror returns
+    R * I on every path."""
+    w = h = 32
+    mirror = rrt.make_material(rrt.MAT_MIRROR, kd=(0.75, 0.75, 0.75))
+    scene = rrt.SceneArrays(materials=[mirror], lights=_distant(rrt), planes=[rrt.make_plane((0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0)])
+    for pos in ((-1.0, 2.0, 0.3), (-2.0, 0.02, 0.0)):   # steep, and grazing (cos ~ 0.01, the reference's third case)
+        cam = rrt.Camera(pos, (0.0, 0.0, 0.0), 0.02, 0.0, None, w, h)
+        l = _specular_radiances(rrt, gpu_ctx, scene, cam, w, h, seed=8)
+        np.testing.assert_allclose(l / INTENSITY, 0.75, rtol=1e-5)

@@ -322,12 +322,12 @@ def test_tonemap_matches_the_oracle_pixel(rrt, oracle_binding):
 
 def test_refused_threads_change_nothing(rrt):
     """The builder spreads its passes and subtrees over host threads.  When the system refuses a thread
-    (here: a test hook that refuses every creation after the first n) the work runs on the thread that
-    asked for it: same hierarchy, no exception across the C boundary, no abort."""
+    (here: RRT_DEBUG_FAIL_THREADS_AFTER=n in the environment, which refuses every creation after the first n;
+    the library exports no function for it) the work runs on the thread that asked for it: same hierarchy, no
+    exception across the C boundary, no abort."""
     import ctypes as C
     lib = rrt.hip_lib()
-    lib.rrt_debug_fail_threads_after.argtypes = [C.c_int]
-    lib.rrt_debug_fail_threads_after.restype = None
+    assert not hasattr(lib, "rrt_debug_fail_threads_after")
     rng = np.random.default_rng(2)
     n = 150000  # above the builder's threshold for handing subtrees to threads
     centre = rng.uniform(-10, 10, size=(n, 1, 3))
@@ -335,13 +335,16 @@ def test_refused_threads_change_nothing(rrt):
     results = []
     try:
         for allowed in (-1, 0, 1, 3):
-            lib.rrt_debug_fail_threads_after(allowed)
+            if allowed < 0:
+                os.environ.pop("RRT_DEBUG_FAIL_THREADS_AFTER", None)
+            else:
+                os.environ["RRT_DEBUG_FAIL_THREADS_AFTER"] = str(allowed)
             nodes, depth = C.c_uint32(), C.c_uint32()
             bad = lib.rrt_bvh_selfcheck(tri.ctypes.data, n, C.byref(nodes), C.byref(depth))
             assert bad == 0, (allowed, bad)
             results.append((nodes.value, depth.value))
     finally:
-        lib.rrt_debug_fail_threads_after(-1)
+        os.environ.pop("RRT_DEBUG_FAIL_THREADS_AFTER", None)
     assert len(set(results)) == 1, results
 
 

@@ -60,11 +60,29 @@ def main(tag):
     ext = out.get("rrt::k_extend<false>")
     frames = launches.get("rrt::k_primary<false>", 0)  # one primary launch per frame of this workload
     if ext and "hbm_bytes_per_launch" in ext and frames:
+        # every kernel of the frame, for the bench line's other roofline entries
+        per_kernel = {}
+        for name, e in out.items():
+            if "hbm_bytes_per_launch" not in e:
+                continue
+            short = name.replace("rrt::", "").split("<")[0]
+            k = per_kernel.setdefault(short, {"hbm_bytes_per_frame": 0.0, "launches_per_frame": 0.0, "us_per_frame": 0.0,
+                                              "_hit": 0.0, "_miss": 0.0})
+            k["hbm_bytes_per_frame"] += e["hbm_bytes_per_launch"] * e["launches"] / frames
+            k["launches_per_frame"] += e["launches"] / frames
+            k["us_per_frame"] += e["avg_launch_us"] * e["launches"] / frames
+            k["_hit"] += e["counters"].get("TCC_HIT_sum", 0.0)
+            k["_miss"] += e["counters"].get("TCC_MISS_sum", 0.0)
+        for k in per_kernel.values():
+            hit, miss = k.pop("_hit"), k.pop("_miss")
+            k["l2_hit_rate"] = hit / (hit + miss) if hit + miss > 0 else None
+            k["hbm_gb_per_s"] = k["hbm_bytes_per_frame"] / (k["us_per_frame"] * 1e-6) * 1e-9 if k["us_per_frame"] > 0 else None
         with open(os.path.join(dst, "extend_traffic.json"), "w") as f:
             json.dump({"source": tag, "kernel": "k_extend", "workload": "buddha 1920x1080, 256 spp",
                        "hbm_bytes_per_frame": ext["hbm_bytes_per_launch"] * ext["launches"] / frames,
                        "launches_per_frame": ext["launches"] / frames, "avg_launch_us": ext["avg_launch_us"],
-                       "l2_hit_rate": ext.get("l2_hit_rate"), "kernel_fingerprint": kernel_fingerprint()}, f, indent=1)
+                       "l2_hit_rate": ext.get("l2_hit_rate"), "kernels": per_kernel,
+                       "kernel_fingerprint": kernel_fingerprint()}, f, indent=1)
     for name, e in sorted(out.items()):
         print("%-28s launches %4d avg %9.1f us  HBM %8.1f GB/s  L2 hit %.3f" % (
             name, e["launches"], e["avg_launch_us"], e.get("hbm_gb_per_s", 0.0), e.get("l2_hit_rate", 0.0)))
