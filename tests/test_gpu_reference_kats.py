@@ -46,11 +46,11 @@ def test_triangle_vector_first_hit(rrt, gpu_ctx):
 
 def test_triangle_vector_shading_normal(rrt, gpu_ctx):
     """Same vector: the shading normal at that point is normalize(0.5, 0, -1) (blend of the vertex normals).
-    Seen through a render: a camera at (0, 0, -2) looking along +z through a 0.001-degree field of view, so that
-    every camera ray is the vector's ray to within 2e-8; the first-hit buffer holds the shading normals of those that hit."""
+    Seen through a render: a camera at (0, 0, -2) looking along +z through a 0.0001-degree field of view, so that
+    every camera ray meets the triangle within 2e-6 of the vector's ray (the blended normal turns by 0.3 per unit); the first-hit buffer holds the shading normals of those that hit."""
     gpu_ctx.upload_scene(_triangle_scene(rrt))
     w = h = 8
-    cam = rrt.Camera((0.0, 0.0, -2.0), (0.0, 0.0, 0.0), 1e-3, 0.0, None, w, h)
+    cam = rrt.Camera((0.0, 0.0, -2.0), (0.0, 0.0, 0.0), 1e-4, 0.0, None, w, h)
     gpu_ctx.set_camera(cam)
     gpu_ctx.film_alloc(w, h)
     gpu_ctx.set_option(rrt.OPT_AOVS, 1)
@@ -65,7 +65,7 @@ def test_triangle_vector_shading_normal(rrt, gpu_ctx):
     assert 0.3 * 4 * w * h <= hits.sum() <= 0.7 * 4 * w * h
     ns = normal[hits > 0, :3] / hits[hits > 0, None]
     expected = np.array([0.5, 0.0, -1.0]) / np.linalg.norm([0.5, 0.0, -1.0])
-    np.testing.assert_allclose(ns, np.tile(expected, (len(ns), 1)), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ns, np.tile(expected, (len(ns), 1)), rtol=1e-6, atol=2e-6)
 
 
 def _camera_target(rrt, position, target, cells=100):
