@@ -410,7 +410,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         # ---- the other single-GPU configurations, on the same context: a few frames each, untimed parts left out
-        if world == 1 and default_workload and not args.no_other_workloads:
+        if world == 1 and default_workload and not args.no_other_workloads and not args.no_calibrate:
             others = {}
             for key, name, spp_o, steps_o in (("cornell_1080p_1024spp", "cornell", 1024, 2), ("buddha_hard_standin_1080p_256spp", "buddha-hard", 256, 5)):
                 scene_o, rs_o, camera_o, mesh_o, depth_o, clamp_o, workload_o = make_workload(name, W, H, spp_o, "per GPU", args.trios)

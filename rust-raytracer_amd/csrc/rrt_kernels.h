@@ -60,6 +60,11 @@
 #define RRT_TAIL_QUORUM 32
 #endif
 
+// Diagnostic builds only (timing experiments; the results are wrong): the analytic shapes are never looked at.
+#ifndef RRT_DIAG_NO_OTHERS
+#define RRT_DIAG_NO_OTHERS 0
+#endif
+
 namespace rrt {
 
 struct DeviceStats {
@@ -471,7 +476,7 @@ struct ExtendJob {
   }
   RRT_DEV bool advance(bool found, const Hit& tri_hit, const RayPre& r, Ray*) {
     Hit h = tri_hit;
-    if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
+    if (!RRT_DIAG_NO_OTHERS && sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
     hit_surface = h.prim >= 0;
     // shade needs the whole ray, start (for a ray that escaped and still has something to collect) its
     // direction and state
@@ -565,7 +570,7 @@ struct PrimaryJob {
   }
   RRT_DEV bool advance(bool found, const Hit& tri_hit, const RayPre& r, Ray*) {
     Hit h = tri_hit;
-    if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
+    if (!RRT_DIAG_NO_OTHERS && sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
     if (h.prim >= 0) {
       if (h.prim >= sc->n_tris) p.a.trace[slot].ray_o = f4(r.o, 0.0f);  // only the analytic shapes' shading reads it
       p.a.trace[slot].ray_d = f4(r.d, __uint_as_float(0u));
@@ -862,7 +867,7 @@ struct ConnectJob {
   }
   RRT_DEV bool advance(bool found, const Hit&, const RayPre& r, Ray* ray) {
     bool occluded = found;
-    if (!occluded && sc->n_rects + sc->n_planes + sc->n_spheres > 0) {
+    if (!RRT_DIAG_NO_OTHERS && !occluded && sc->n_rects + sc->n_planes + sc->n_spheres > 0) {
       Hit h;
       occluded = intersect_others<true>(sc, r, far, own, light_quad, &h);
     }
@@ -996,7 +1001,7 @@ struct TailJob {
     return false;
   }
   RRT_DEV bool advance(bool found, const Hit& tri_hit, const RayPre& r, Ray* ray) {
-    const bool others = sc->n_rects + sc->n_planes + sc->n_spheres > 0;
+    const bool others = !RRT_DIAG_NO_OTHERS && sc->n_rects + sc->n_planes + sc->n_spheres > 0;
     if (stage != 0) {
       bool occluded = found;
       if (!occluded && others) {
@@ -1213,7 +1218,7 @@ struct IntersectJob {
   }
   RRT_DEV bool advance(bool, const Hit& tri_hit, const RayPre& r, Ray*) {
     Hit h = tri_hit;
-    if (sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
+    if (!RRT_DIAG_NO_OTHERS && sc->n_rects + sc->n_planes + sc->n_spheres > 0) intersect_others<false>(sc, r, h.t, -1, -1, &h);
     int id = h.prim;
     float t = h.prim >= 0 ? h.t : 0.0f;
     if (id >= 0) {
@@ -1280,7 +1285,7 @@ struct OccludedJob {
   }
   RRT_DEV bool advance(bool found, const Hit&, const RayPre& r, Ray*) {
     bool occluded = found;
-    if (!occluded && sc->n_rects + sc->n_planes + sc->n_spheres > 0) {
+    if (!RRT_DIAG_NO_OTHERS && !occluded && sc->n_rects + sc->n_planes + sc->n_spheres > 0) {
       Hit h;
       occluded = intersect_others<true>(sc, r, far, -1, -1, &h);
     }

@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/sqp_$V
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export RRT_HIP_LIB=$REPO/build_ab/librrt_hip_$V.so RRT_DEVICE_BVH_OVERRIDE=${BVH:-1}
-ARGS="--steps 1 --warmup 0 --spp 256 --cpu-seconds 0 --no-calibrate"
+ARGS="--steps 1 --warmup 0 --spp 256 --cpu-seconds 0 --no-calibrate --no-other-workloads"
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_FLAT --output-format csv -d $OUT/p1 -- python3 $REPO/bench.py $ARGS > $OUT/b1.json || exit 1
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
