@@ -120,6 +120,7 @@ struct rrt_ctx {
   uint32_t n_nodes = 0;
   uint64_t bvh_bytes = 0;
   uint32_t n_tris = 0, bvh_max_depth = 0;
+  bool scene_has_specular = false;   // some material has a lobe whose sample is flagged specular (mirror lobe, glass)
   bool bvh_built_on_device = false;
   double bvh_build_seconds = 0.0;   // device build only
   std::string bvh_fallback_reason;  // why the automatic mode built on the host after all (empty: it did not)
@@ -468,6 +469,11 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_connect, hipEventDisableTiming));
   }
   bool connect_outstanding = false;  // a connect on the side stream that the main stream has not joined yet
+  // With one sample per slot the start kernel only serves rays that left the scene after a specular bounce
+  // (they still owe the environment term).  A scene without a specular lobe, or without anything to collect
+  // out there, never queues one: the launch -- which would wait behind the visibility rays of the previous
+  // iteration for a free CU just to find its queue empty -- is left out.
+  const bool start_has_work = p.single == 0 || (ctx->scene_has_specular && p.escape_lit != 0);
   // the tail kernel: one sample per slot only; not while traversal steps are being counted per kernel
   const bool use_tail = p.single != 0 && ctx->tail_paths > 0 && !ctx->count_traversal;
   // Whichever way the pass is left: the caller's stream waits for a connect still running on the side
@@ -501,9 +507,11 @@ int launch_pass(rrt_ctx* ctx, RenderParams& p) {
         else hipLaunchKernelGGL(k_primary<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera);
         if ((rc = record_end(ctx)) != RRT_OK) return rc;
       } else {
-        if ((rc = record_begin(ctx, 0)) != RRT_OK) return rc;
-        hipLaunchKernelGGL(k_start, dim3(grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, parity);
-        if ((rc = record_end(ctx)) != RRT_OK) return rc;
+        if (start_has_work) {
+          if ((rc = record_begin(ctx, 0)) != RRT_OK) return rc;
+          hipLaunchKernelGGL(k_start, dim3(grid), dim3(kBlock), 0, ctx->stream, p, ctx->camera, parity);
+          if ((rc = record_end(ctx)) != RRT_OK) return rc;
+        }
         if ((rc = record_begin(ctx, 1)) != RRT_OK) return rc;
         if (ctx->count_traversal) hipLaunchKernelGGL(k_extend<true>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, parity);
         else hipLaunchKernelGGL(k_extend<false>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, p, parity);
@@ -883,7 +891,11 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   st.env_w = (int)sd->env_w;
   st.env_h = (int)sd->env_h;
   std::vector<DeviceMaterial> mats(sd->n_materials);
-  for (uint32_t i = 0; i < sd->n_materials; ++i) mats[i] = digest_material(sd->materials[i]);
+  ctx->scene_has_specular = false;
+  for (uint32_t i = 0; i < sd->n_materials; ++i) {
+    mats[i] = digest_material(sd->materials[i]);
+    if (mats[i].has_trans || mats[i].spec_kind == SPEC_MIRROR_DIELECTRIC || mats[i].spec_kind == SPEC_MIRROR_NOOP) ctx->scene_has_specular = true;
+  }
 
   const uint32_t max_depth = device_build ? device_depth : bvh.max_depth;
   ctx->n_nodes = device_build ? device_nodes : bvh.n_nodes;

@@ -610,10 +610,13 @@ struct PrimaryJob {
   }
 };
 
-// (Bounded to 4 waves per SIMD = 128 registers: the kernel sits right at that edge, and one register
-// more would cost a quarter of its rays in flight.)
+// (Bounded to 5 waves per SIMD = 96 registers.  Compiled without SLP vectorisation the kernel wants 100; held to
+// 96 it spills a few scalar registers and gains a fifth wave: 16.0 -> 14.9 ms on the bench frame.)
+#ifndef RRT_PRIMARY_WAVES
+#define RRT_PRIMARY_WAVES 5
+#endif
 template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock, 4) k_primary(RenderParams p, CameraParams cam) {
+__global__ void __launch_bounds__(kTraceBlock, RRT_PRIMARY_WAVES) k_primary(RenderParams p, CameraParams cam) {
   RRT_DECLARE_TRACE_STACK();
   RRT_DECLARE_SHAPES();
   const SceneTables* sc = shapes_to_lds(p.scene, rrt_shape_words);

@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rust-raytracer_amd", "csrc")
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-       "-fgpu-flush-denormals-to-zero", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Rpass-analysis=kernel-resource-usage",
+       "-fgpu-flush-denormals-to-zero", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Rpass-analysis=kernel-resource-usage",
        *sys.argv[1:], "-o", "/tmp/rrt_resources.so", "rrt_api.hip", "bvh_build.cpp", "bvh_build_device.hip", "-ldl"]
 out = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True).stderr
 cur = None
