@@ -47,9 +47,11 @@ stress = _load("rust_raytracer_amd.stress", "rust-raytracer_amd/stress.py")
 rrbuild = _load("rust_raytracer_amd.build", "rust-raytracer_amd/build.py")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-# algorithmic bytes per ray: 64 B per BVH node visited (corner, grid exponents, four links, four boxes of six bytes), 36 B per
-# triangle tested (nine f32 positions), 32 B ray in, 16 B hit out
+# algorithmic bytes per ray: 64 B per BVH node visited (two boxes of six f32 and the links, the figure the roofline is
+# defined on), 36 B per triangle tested (nine f32 positions), 32 B ray in, 16 B hit out.  The node as stored is smaller
+# (48 B: four links, four boxes of six bytes, corner and grid shifts); the roofline entry carries the rate on that as well.
 NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 64, 36, 32, 16
+NODE_BYTES_STORED, TRI_BYTES_STORED = 48, 48
 STATE_BYTES_PER_BOUNCE = 264  # wavefront path state read + written per shaded bounce
 
 
@@ -331,7 +333,9 @@ def main():
             def entry(name, k, n_rays, launches, ms):
                 bytes_per_ray = per_ray[k][0] * NODE_BYTES + per_ray[k][1] * TRI_BYTES + RAY_BYTES + HIT_BYTES
                 gbs = n_rays * bytes_per_ray / (ms * 1e-3) * 1e-9 if ms > 0 else 0.0
-                return {"kernel": name, "rays_per_launch": n_rays / max(launches, 1), "bytes_per_ray": bytes_per_ray,
+                fetched_per_ray = per_ray[k][0] * NODE_BYTES_STORED + per_ray[k][1] * TRI_BYTES_STORED + RAY_BYTES + HIT_BYTES
+                return {"kernel": name, "bytes_fetched_per_ray": fetched_per_ray,
+                        "fetched_gb_per_s": n_rays * fetched_per_ray / (ms * 1e-3) * 1e-9 if ms > 0 else 0.0, "rays_per_launch": n_rays / max(launches, 1), "bytes_per_ray": bytes_per_ray,
                         "nodes_per_ray": per_ray[k][0], "tris_per_ray": per_ray[k][1], "share_of_rays_entering_the_hierarchy": per_ray[k][2],
                         "launches": int(launches), "avg_launch_ms": ms / max(launches, 1), "algorithmic_gb_per_s": gbs,
                         "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
@@ -352,6 +356,9 @@ def main():
                         "unit": "GB/s", "frac": e["algorithmic_gb_per_s"] / HBM_PEAK_GBS, "traffic": traffic,
                         "hbm_gb_per_s": hbm_gbs, "l2_hit_rate": l2,
                         "bytes_per_ray": e["bytes_per_ray"], "nodes_per_ray": e["nodes_per_ray"],
+                        # the same with the records as stored (48-byte nodes, 48-byte triangle records)
+                        "bytes_fetched_per_ray": e["bytes_fetched_per_ray"], "fetched_gb_per_s": e["fetched_gb_per_s"],
+                        "frac_fetched": e["fetched_gb_per_s"] / HBM_PEAK_GBS,
                         "tris_per_ray": e["tris_per_ray"], "launches": e["launches"], "avg_launch_ms": e["avg_launch_ms"],
                         "rays_per_launch": e["rays_per_launch"]}
             if prof_note:

@@ -309,6 +309,7 @@ struct Collapser {
   const Node2* in;
   uint32_t* below = nullptr;   // per binary node: 4-wide nodes in the subtree it roots (0 if it is adopted away)
   BvhNode* out = nullptr;
+  BvhGrid grid = {};
   std::atomic<uint32_t> max_depth{0};
   std::atomic<int> free_threads{0};
   std::atomic<bool> failed{false};
@@ -399,49 +400,25 @@ struct Collapser {
     while (depth > d && !max_depth.compare_exchange_weak(d, depth, std::memory_order_relaxed)) {}
     Child c[4];
     const int n = gather(old_i, c);
+    const bool empty = !(c[0].box.mx[0] >= c[0].box.mn[0]);  // a scene without triangles
     BvhNode node;
     std::memset(&node, 0, sizeof(node));
-    // the node's own box, and per axis the smallest power-of-two grid step that spans it in 255 steps
-    Box all = c[0].box;
-    for (int i = 1; i < n; ++i)
-      for (int k = 0; k < 3; ++k) {
-        all.mn[k] = std::min(all.mn[k], c[i].box.mn[k]);
-        all.mx[k] = std::max(all.mx[k], c[i].box.mx[k]);
-      }
-    const bool empty = !(all.mx[0] >= all.mn[0]);  // a scene without triangles
-    double step[3];
-    for (int k = 0; k < 3; ++k) {
-      node.origin[k] = empty ? 0.0f : all.mn[k];
-      const double extent = empty ? 0.0 : (double)all.mx[k] - (double)all.mn[k];
-      int e = -126;
-      if (extent > 0.0) {
-        int ex;
-        std::frexp(extent / 255.0, &ex);  // extent / 255 = m * 2^ex with m in [0.5, 1): 2^ex is at least as large
-        e = std::min(std::max(ex, -126), 127);
-      }
-      node.exp[k] = (uint8_t)(e + 127);
-      step[k] = std::ldexp(1.0, e);
-    }
+    float mn[4][3], mx[4][3];
+    for (int i = 0; i < n; ++i)
+      for (int k = 0; k < 3; ++k) { mn[i][k] = c[i].box.mn[k]; mx[i][k] = c[i].box.mx[k]; }
+    encode_node_boxes(grid, mn, mx, empty ? 0 : n, &node);
     uint32_t at[4] = {0, 0, 0, 0};
     uint32_t next = me + 1;
     for (int i = 0; i < 4; ++i) {
-      if (i < n && !empty) {
-        for (int k = 0; k < 3; ++k) {
-          // differences of floats and divisions by a power of two are exact in double
-          const double lo = std::floor(((double)c[i].box.mn[k] - (double)node.origin[k]) / step[k]);
-          const double hi = std::ceil(((double)c[i].box.mx[k] - (double)node.origin[k]) / step[k]);
-          node.qlo[k][i] = (uint8_t)std::min(std::max(lo, 0.0), 255.0);
-          node.qhi[k][i] = (uint8_t)std::min(std::max(hi, 0.0), 255.0);
-        }
-        node.child[i] = c[i].ref;
-        if (c[i].inner) {
-          at[i] = next;
-          node.child[i] = (int32_t)next;
-          next += below[c[i].ref];
-        }
-      } else {
-        for (int k = 0; k < 3; ++k) { node.qlo[k][i] = 255; node.qhi[k][i] = 0; }
-        node.child[i] = ~0;  // replaced by child 0's link below (stays as it is in a scene without triangles, which is never traversed)
+      // a slot without a child: replaced by child 0's link below (stays as it is in a scene without
+      // triangles, which is never traversed)
+      node.child[i] = ~0;
+      if (i >= n || empty) continue;
+      node.child[i] = c[i].ref;
+      if (c[i].inner) {
+        at[i] = next;
+        node.child[i] = (int32_t)next;
+        next += below[c[i].ref];
       }
     }
     if (!empty)
@@ -518,6 +495,16 @@ bool build_bvh_impl(const float* tri_pos, uint32_t n_tris, uint32_t threads, Bvh
   if (posix_memalign((void**)&nodes, alignof(BvhNode), sizeof(BvhNode) * (size_t)n_nodes) != 0) return false;
   out->nodes = nodes;  // (the caller frees it if anything below fails)
   col.out = nodes;
+  {
+    // the root's two children span every triangle (an absent one has an inverted box and adds nothing)
+    const Node2& root = scratch[0];
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = std::min(root.lmin[k], root.rmin[k]);
+      mx[k] = std::max(root.lmax[k], root.rmax[k]);
+    }
+    col.grid = out->grid = make_bvh_grid(mn, mx);
+  }
   col.emit(0, 0, 1);
   if (col.failed) return false;
   if (std::getenv("RRT_BVH_TIMING"))
@@ -528,6 +515,25 @@ bool build_bvh_impl(const float* tri_pos, uint32_t n_tris, uint32_t threads, Bvh
   return true;
 }
 }  // namespace
+
+BvhGrid make_bvh_grid(const float mn[3], const float mx[3]) {
+  BvhGrid g;
+  for (int k = 0; k < 3; ++k) {
+    const bool finite = std::isfinite(mn[k]) && std::isfinite(mx[k]) && mx[k] >= mn[k];
+    g.base[k] = finite ? mn[k] : 0.0f;
+    int e = 0;
+    if (finite && mx[k] > mn[k]) {
+      std::frexp(((double)mx[k] - (double)mn[k]) / 65535.0, &e);  // = m * 2^e with m in [0.5, 1): 2^e is at least as large
+      // far inside the range of a float, so that neither the step times a ray's reciprocal direction
+      // nor the smallest node step underflows
+      e = std::min(std::max(e, -80), 100);
+      // (rounding of base + 65535 * step is seen to by the node encoder, which checks every plane it writes)
+    }
+    g.step[k] = (float)std::ldexp(1.0, e);
+    g.inv_step[k] = (float)std::ldexp(1.0, -e);
+  }
+  return g;
+}
 
 // Never throws: running out of memory or of threads anywhere below gives false (a thread that cannot
 // be started is not an error: its share of the work runs on the thread that wanted it).
@@ -560,12 +566,11 @@ bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuild
 
 namespace {
 
-// The box a traversing lane decodes for child i of a node, in double (every term is exact there).
-void decoded_box(const BvhNode& n, int i, double* mn, double* mx) {
+// The box a traversing lane decodes for child i of a node, in double.
+void decoded_box(const BvhGrid& g, const BvhNode& n, int i, double* mn, double* mx) {
   for (int k = 0; k < 3; ++k) {
-    const double step = std::ldexp(1.0, (int)n.exp[k] - 127);
-    mn[k] = (double)n.origin[k] + n.qlo[k][i] * step;
-    mx[k] = (double)n.origin[k] + n.qhi[k][i] * step;
+    mn[k] = node_plane(g, n, k, n.qlo[k][i]);
+    mx[k] = node_plane(g, n, k, n.qhi[k][i]);
   }
 }
 
@@ -602,7 +607,7 @@ struct Validator {
       if (!child_present(n, i)) continue;
       double cmn[3], cmx[3], dmn[3], dmx[3];
       bounds(n.child[i], depth + (n.child[i] >= 0 ? 1 : 0), cmn, cmx);
-      decoded_box(n, i, dmn, dmx);
+      decoded_box(b.grid, n, i, dmn, dmx);
       for (int k = 0; k < 3; ++k) {
         if (!(cmn[k] >= dmn[k] && cmx[k] <= dmx[k])) ++bad;
         mn[k] = std::min(mn[k], cmn[k]);

@@ -3,7 +3,7 @@
 // The reference builds its hierarchy on one host thread (`Bvh::build(&mut objects)`, src/scene.rs:196)
 // and uses it only as a conservative candidate filter (src/renderer.rs:226-246), so any sound
 // hierarchy over the same triangles gives the same hits.  This builder produces the same kind of
-// result as the host one -- 64-byte 4-wide nodes with 8-bit child boxes in depth-first order, leaves
+// result as the host one -- 48-byte 4-wide nodes with 8-bit child boxes in depth-first order, leaves
 // of up to four triangles stored contiguously, leaf-ordered triangle records -- from kernels:
 //
 //   1. centroid bounds, 63-bit Morton codes, radix sort (hipCUB)
@@ -352,69 +352,44 @@ __global__ void __launch_bounds__(kBuildBlock) k_below(uint32_t begin, uint32_t 
 }
 
 // Top-down again: the children's positions in depth-first order, and the node itself
-// (origin, per-axis power-of-two grid step, child boxes rounded outwards onto that grid).
+// (corner on the scene's grid, per-axis shift, child boxes rounded outwards: encode_node_boxes).
 __global__ void __launch_bounds__(kBuildBlock) k_emit(uint32_t begin, uint32_t end, const PNode* __restrict__ nodes,
                                                       const uint32_t* __restrict__ cnt, const uint8_t* __restrict__ role,
                                                       const uint32_t* __restrict__ first, const int4* __restrict__ wide_children,
                                                       const uint32_t* __restrict__ below, uint32_t* __restrict__ offset,
                                                       uint32_t* __restrict__ depth, uint32_t* __restrict__ max_depth,
-                                                      BvhNode* __restrict__ out) {
+                                                      BvhGrid grid, BvhNode* __restrict__ out) {
   const uint32_t id = begin + blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= end || role[id] != kRoleWide) return;
   const int4 ch = wide_children[id];
   const int32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
   const uint32_t me = offset[id], d = depth[id];
   atomicMax(max_depth, d);
-  PNode box[4];
+  float mn[4][3], mx[4][3];
   int n = 0;
-  float all_mn[3] = {INFINITY, INFINITY, INFINITY}, all_mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = 0; i < 4; ++i) {
     if (c[i] < 0) break;
-    box[i] = nodes[c[i]];
+    const PNode box = nodes[c[i]];
     for (int k = 0; k < 3; ++k) {
-      all_mn[k] = fminf(all_mn[k], box[i].mn[k]);
-      all_mx[k] = fmaxf(all_mx[k], box[i].mx[k]);
+      mn[i][k] = box.mn[k];
+      mx[i][k] = box.mx[k];
     }
     ++n;
   }
   BvhNode node;
-  double step[3];
-  for (int k = 0; k < 3; ++k) {
-    node.origin[k] = all_mn[k];
-    const double extent = (double)all_mx[k] - (double)all_mn[k];
-    int e = -126;
-    if (extent > 0.0) {
-      int ex;
-      (void)frexp(extent / 255.0, &ex);  // extent / 255 = m * 2^ex with m in [0.5, 1): 2^ex is at least as large
-      e = min(max(ex, -126), 127);
-    }
-    node.exp[k] = (uint8_t)(e + 127);
-    step[k] = ldexp(1.0, e);
-  }
-  node.pad0 = 0;
-  node.pad1[0] = node.pad1[1] = 0;
+  encode_node_boxes(grid, mn, mx, n, &node);
   uint32_t next = me + 1;
   for (int i = 0; i < 4; ++i) {
-    if (i < n) {
-      for (int k = 0; k < 3; ++k) {
-        // differences of floats and divisions by a power of two are exact in double
-        const double lo = floor(((double)box[i].mn[k] - (double)node.origin[k]) / step[k]);
-        const double hi = ceil(((double)box[i].mx[k] - (double)node.origin[k]) / step[k]);
-        node.qlo[k][i] = (uint8_t)fmin(fmax(lo, 0.0), 255.0);
-        node.qhi[k][i] = (uint8_t)fmin(fmax(hi, 0.0), 255.0);
-      }
-      const uint32_t x = (uint32_t)c[i];
-      if (role[x] == kRoleWide) {
-        node.child[i] = (int32_t)next;
-        offset[x] = next;
-        depth[x] = d + 1;
-        next += below[x];
-      } else {
-        node.child[i] = ~(int32_t)((first[x] << 2) | (cnt[x] - 1));
-      }
+    node.child[i] = 0;
+    if (i >= n) continue;
+    const uint32_t x = (uint32_t)c[i];
+    if (role[x] == kRoleWide) {
+      node.child[i] = (int32_t)next;
+      offset[x] = next;
+      depth[x] = d + 1;
+      next += below[x];
     } else {
-      for (int k = 0; k < 3; ++k) { node.qlo[k][i] = 255; node.qhi[k][i] = 0; }
-      node.child[i] = 0;
+      node.child[i] = ~(int32_t)((first[x] << 2) | (cnt[x] - 1));
     }
   }
   for (int i = n; i < 4; ++i) node.child[i] = node.child[0];  // a slot without a child repeats the first link
@@ -602,8 +577,11 @@ int build_bvh_device(const float* tri_pos, const float* tri_nrm, const uint32_t*
     hipLaunchKernelGGL(k_below, dim3(blocks_for(e - b)), dim3(kBuildBlock), 0, stream, b, e, d_role, d_wide, d_below);
   }
   uint32_t n_nodes = 0;
+  PNode root_box;  // the last merge: its box spans every triangle
   BUILD_TRY(hipMemcpyAsync(&n_nodes, d_below + root, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  BUILD_TRY(hipMemcpyAsync(&root_box, d_pnodes + root, sizeof(PNode), hipMemcpyDeviceToHost, stream));
   BUILD_TRY(hipStreamSynchronize(stream));
+  out->grid = make_bvh_grid(root_box.mn, root_box.mx);
   if (n_nodes == 0 || n_nodes > n) {
     *error = "device BVH build: bad node count";
     return RRT_E_DEVICE;
@@ -626,7 +604,7 @@ int build_bvh_device(const float* tri_pos, const float* tri_nrm, const uint32_t*
   for (size_t r = rounds; r-- > 0;) {
     const uint32_t b = round_begin[r], e = round_begin[r + 1];
     hipLaunchKernelGGL(k_emit, dim3(blocks_for(e - b)), dim3(kBuildBlock), 0, stream, b, e, d_pnodes, d_cnt, d_role, d_first, d_wide,
-                       d_below, d_offset, d_depth, d_max_depth, d_nodes);
+                       d_below, d_offset, d_depth, d_max_depth, out->grid, d_nodes);
   }
   // ---- 5. triangle records
   hipLaunchKernelGGL(k_records, dim3(blocks_for(n)), dim3(kBuildBlock), 0, stream, d_pos, d_nrm, d_mat, d_order, n, d_tris, d_shade);

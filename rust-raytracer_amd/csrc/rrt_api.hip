@@ -109,6 +109,7 @@ struct rrt_ctx {
   // scene
   bool have_scene = false;
   BvhNode* d_nodes = nullptr;
+  BvhGrid grid = {};  // of the hierarchy in d_nodes
   TriIsect* d_tris = nullptr;
   TriShade* d_tri_shade = nullptr;
   DeviceMaterial* d_materials = nullptr;
@@ -717,6 +718,7 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
   bool device_build = sd->n_tris >= kDeviceBuildMinTris &&
                       (ctx->device_bvh == 1 || (ctx->device_bvh == 2 && sd->n_tris >= kAutoDeviceBuildTris));
   uint32_t device_depth = 0, device_nodes = 0;
+  BvhGrid device_grid = {};
   ctx->bvh_build_seconds = 0.0;
   ctx->bvh_fallback_reason.clear();
   if (device_build) {
@@ -739,6 +741,7 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
     } else {
       device_depth = built.max_depth;
       device_nodes = built.n_nodes;
+      device_grid = built.grid;
       ctx->bvh_build_seconds = built.seconds;
       if (std::getenv("RRT_BVH_TIMING"))
         std::fprintf(stderr, "bvh build on the device: %u triangles, %u clustering rounds, %u 4-wide nodes, depth %u, %.3f s\n", sd->n_tris,
@@ -899,6 +902,7 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
 
   const uint32_t max_depth = device_build ? device_depth : bvh.max_depth;
   ctx->n_nodes = device_build ? device_nodes : bvh.n_nodes;
+  ctx->grid = device_build ? device_grid : bvh.grid;
   ctx->bvh_built_on_device = device_build;
   // every 4-wide node on a ray's way down leaves at most 3 entries on the traversal stack
   if (3ull * max_depth + 1 > (uint64_t)kStackDepth) {
@@ -1226,6 +1230,7 @@ int render_impl(rrt_ctx* ctx, const rrt_settings* s, uint32_t sample_begin, uint
   std::memset(&p, 0, sizeof(p));
   p.a = ctx->arrays;
   p.nodes = ctx->d_nodes;
+  p.grid = ctx->grid;
   p.tris = ctx->d_tris;
   p.tri_shade = ctx->d_tri_shade;
   p.materials = ctx->d_materials;
@@ -1314,7 +1319,7 @@ int rrt_intersect(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_t* prim_
     if (e == hipSuccess) {
       e = hipMemsetAsync(ctx->d_work, 0, sizeof(uint32_t), ctx->stream);
       hipLaunchKernelGGL(k_intersect, dim3(std::min(grid_for(n), kTraceGridBlocks)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes,
-                         ctx->d_tris, ctx->d_tri_pos, ctx->d_exact, ctx->d_scene, d_rays, n, d_prim, d_t, ctx->d_work);
+                         ctx->grid, ctx->d_tris, ctx->d_tri_pos, ctx->d_exact, ctx->d_scene, d_rays, n, d_prim, d_t, ctx->d_work);
       if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(prim_id, d_prim, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
@@ -1350,7 +1355,7 @@ int rrt_intersect_noalloc(rrt_ctx* ctx, const float* org_dir, uint32_t n, int32_
   HIP_TRY(ctx, hipMemsetAsync(d_cursor, 0, kScratchCursorBytes, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_rays, org_dir, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_intersect, dim3(std::min(grid_for(n), kTraceGridBlocks)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes,
-                     ctx->d_tris, ctx->d_tri_pos, ctx->d_exact, ctx->d_scene, d_rays, n, d_prim, d_t, d_cursor);
+                     ctx->grid, ctx->d_tris, ctx->d_tri_pos, ctx->d_exact, ctx->d_scene, d_rays, n, d_prim, d_t, d_cursor);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(prim_id, d_prim, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(t, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1375,7 +1380,7 @@ int rrt_occluded(rrt_ctx* ctx, const float* org_dir_tmax, uint32_t n, uint8_t* h
     if (e == hipSuccess) {
       e = hipMemsetAsync(ctx->d_work, 0, sizeof(uint32_t), ctx->stream);
       hipLaunchKernelGGL(k_occluded, dim3(std::min(grid_for(n), kTraceGridBlocks)), dim3(kBlock), 0, ctx->stream, ctx->d_nodes,
-                         ctx->d_tris, ctx->d_scene, d_rays, n, d_hit, ctx->d_work);
+                         ctx->grid, ctx->d_tris, ctx->d_scene, d_rays, n, d_hit, ctx->d_work);
       if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(hit, d_hit, (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
@@ -1502,6 +1507,7 @@ int64_t rrt_bvh_check_uploaded(rrt_ctx* ctx, const float* tri_pos, uint32_t n_tr
   BvhBuildResult b;
   b.n_nodes = ctx->n_nodes;
   b.max_depth = ctx->bvh_max_depth;
+  b.grid = ctx->grid;
   b.nodes = (BvhNode*)std::malloc(sizeof(BvhNode) * std::max<size_t>(ctx->n_nodes, 1));
   b.order = (uint32_t*)std::malloc(sizeof(uint32_t) * std::max<size_t>(n_tris, 1));
   TriIsect* recs = (TriIsect*)std::malloc(sizeof(TriIsect) * std::max<size_t>(n_tris, 1));

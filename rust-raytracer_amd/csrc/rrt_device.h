@@ -3,6 +3,7 @@
 // is structure-of-arrays or 16-byte records so that one lane fetches a whole
 // record with dwordx4 loads.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #include <string>
@@ -20,29 +21,99 @@ struct uint4 { uint32_t x, y, z, w; };
 
 namespace rrt {
 
-// One 4-wide BVH node, 64 B = four 16-byte loads.  The boxes of up to four children are stored as
-// 8-bit offsets from the node's own corner: plane = origin[k] + q * 2^(exp[k] - 127), rounded outwards
-// by the builder, so a decoded box always contains the exact one (at most 1/255 of the node's extent
-// looser per side).  child >= 0: index of an inner node.  child < 0: a leaf of 1..4 triangles of the
-// leaf-ordered triangle arrays, ~child = first << 2 | (count - 1).  A slot without a child holds an
-// inverted box (qlo = 255, qhi = 0 on every axis), which no ray enters, and repeats the link of
-// child 0: should rounding ever let a ray into it -- only a node without any extent can -- the ray
-// visits that child twice, which is harmless.
-// Four wide rather than two: half the steps per ray.  Compressed rather than six floats per child:
-// what bounds traversal is the number of 16-byte loads the lanes of a wave issue to scattered
-// addresses -- the memory pipeline of a CU retires about one such load per lane and clock, whatever
-// the cache level it is served from -- and a node costs four of them instead of seven.
-struct alignas(64) BvhNode {
-  float origin[3];      // minimum corner of the union of the children
-  uint8_t exp[3];       // per axis: biased exponent of the grid step (the exponent field of a float)
-  uint8_t pad0;
-  int32_t child[4];
-  uint8_t qlo[3][4];    // [axis][child]: grid steps from origin to the child's minimum (rounded down)
-  uint8_t qhi[3][4];    // ... to its maximum (rounded up)
-  uint32_t pad1[2];
+// The grid of one hierarchy, on which the corners of its nodes lie: 65535 steps of a power of two per
+// axis from the minimum corner of all triangles span the scene.  Wave-uniform in every kernel.
+struct BvhGrid {
+  float base[3];      // minimum corner of all triangles
+  float step[3];      // 2^e, the smallest with base + 65535 * step >= the maximum corner
+  float inv_step[3];  // 2^-e
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+// One 4-wide BVH node, 48 B = three 16-byte loads.  The node's own corner is a point of the scene's
+// 16-bit grid, corner[k] steps from its base (rounded down, so at most one step below the node's true
+// minimum).  The boxes of up to four children are 8-bit offsets from that corner on a grid of the
+// node's own: plane = base[k] + (corner[k] + q * 2^shift[k]) * step[k], with shift[k] -- signed, 5 bits
+// -- the smallest for which 255 steps reach the node's maximum, and q rounded outwards by the builder,
+// so a decoded box always contains the exact one (at most 1/255 of the node's extent looser per side).
+// Every term is a dyadic rational of few bits: the decoded planes are exact real numbers in double
+// arithmetic, and the kernels never form them -- they go from q straight to the distance along the ray.
+// child >= 0: index of an inner node.  child < 0: a leaf of 1..4 triangles of the leaf-ordered triangle
+// arrays, ~child = first << 2 | (count - 1).  A slot without a child holds an inverted box (qlo = 255,
+// qhi = 0 on every axis), which no ray enters, and repeats the link of child 0: should rounding ever
+// let a ray into it -- only a node without any extent can -- the ray visits that child twice, which is
+// harmless.
+// Four wide rather than two: half the steps per ray.  Compressed rather than six floats per child, and
+// the corner on a scene-wide grid rather than three floats: what bounds traversal is the number of
+// 16-byte loads the lanes of a wave issue to scattered addresses -- the memory pipeline of a CU
+// retires about one such load per lane and clock, whatever the cache level it is served from -- and a
+// node costs three of them instead of seven.
+struct alignas(16) BvhNode {
+  int32_t child[4];
+  uint8_t qlo[3][4];    // [axis][child]: node-grid steps from the corner to the child's minimum (rounded down)
+  uint8_t qhi[3][4];    // ... to its maximum (rounded up)
+  uint16_t corner[3];   // scene-grid steps from BvhGrid::base to the node's corner
+  uint16_t shift;       // three signed 5-bit fields, x lowest: log2 of the node-grid step in scene-grid steps
+};
+static_assert(sizeof(BvhNode) == 48, "BvhNode must be 48 bytes");
+constexpr int kNodeShiftMin = -16, kNodeShiftMax = 15;
 RRT_HD inline bool child_present(const BvhNode& n, int i) { return n.qlo[0][i] <= n.qhi[0][i]; }
+RRT_HD inline int node_shift(const BvhNode& n, int k) {
+  const int f = (n.shift >> (5 * k)) & 31;
+  return f >= 16 ? f - 32 : f;
+}
+// Plane q (0..255) of the node's grid on axis k.  corner + q * 2^shift has at most 40 significant bits and the
+// step is a power of two, so the only rounding is that of the final sum, and the result is monotonic in q.
+RRT_HD inline double node_plane(const BvhGrid& g, uint32_t corner, int shift, int k, uint32_t q) {
+  return (double)g.base[k] + ((double)corner + ldexp((double)q, shift)) * (double)g.step[k];
+}
+RRT_HD inline double node_plane(const BvhGrid& g, const BvhNode& n, int k, uint32_t q) {
+  return node_plane(g, n.corner[k], node_shift(n, k), k, q);
+}
+
+// Fills the boxes of a node from those of its n (0..4) children: corner, shifts, qlo, qhi; slots from n on
+// get the inverted box.  Every decoded plane is checked with node_plane itself, the expression the
+// validator uses, so the boxes contain their children whatever the rounding on the way.
+RRT_HD inline void encode_node_boxes(const BvhGrid& g, const float (*mn)[3], const float (*mx)[3], int n, BvhNode* node) {
+  node->shift = 0;
+  for (int k = 0; k < 3; ++k) {
+    node->corner[k] = 0;
+    for (int i = 0; i < 4; ++i) { node->qlo[k][i] = 255; node->qhi[k][i] = 0; }
+    if (n <= 0) continue;
+    float all_mn = mn[0][k], all_mx = mx[0][k];
+    for (int i = 1; i < n; ++i) {
+      all_mn = mn[i][k] < all_mn ? mn[i][k] : all_mn;
+      all_mx = mx[i][k] > all_mx ? mx[i][k] : all_mx;
+    }
+    double c = floor(((double)all_mn - (double)g.base[k]) * (double)g.inv_step[k]);
+    c = c < 0.0 ? 0.0 : (c > 65535.0 ? 65535.0 : c);
+    uint32_t corner = (uint32_t)c;
+    while (corner > 0 && node_plane(g, corner, 0, k, 0) > (double)all_mn) --corner;
+    // the smallest shift whose 255 steps reach the far side
+    const double reach = ((double)all_mx - node_plane(g, corner, 0, k, 0)) * (double)g.inv_step[k] / 255.0;
+    int shift = kNodeShiftMin;
+    if (reach > 0.0) {
+      int e = 0;
+      (void)frexp(reach, &e);  // reach = m * 2^e with m in [0.5, 1): 2^e >= reach
+      shift = e < kNodeShiftMin ? kNodeShiftMin : (e > kNodeShiftMax ? kNodeShiftMax : e);
+    }
+    while (shift < kNodeShiftMax && node_plane(g, corner, shift, k, 255) < (double)all_mx) ++shift;
+    node->corner[k] = (uint16_t)corner;
+    node->shift = (uint16_t)(node->shift | ((uint32_t)(shift & 31) << (5 * k)));
+    const double origin = node_plane(g, corner, shift, k, 0);
+    const double inv_node_step = ldexp((double)g.inv_step[k], -shift);
+    for (int i = 0; i < n; ++i) {
+      double lo = floor(((double)mn[i][k] - origin) * inv_node_step);
+      double hi = ceil(((double)mx[i][k] - origin) * inv_node_step);
+      lo = lo < 0.0 ? 0.0 : (lo > 255.0 ? 255.0 : lo);
+      hi = hi < 0.0 ? 0.0 : (hi > 255.0 ? 255.0 : hi);
+      uint32_t qlo = (uint32_t)lo, qhi = (uint32_t)hi;
+      while (qlo > 0 && node_plane(g, corner, shift, k, qlo) > (double)mn[i][k]) --qlo;
+      while (qhi < 255 && node_plane(g, corner, shift, k, qhi) < (double)mx[i][k]) ++qhi;
+      node->qlo[k][i] = (uint8_t)qlo;
+      node->qhi[k][i] = (uint8_t)qhi;
+    }
+  }
+}
 
 // Intersection record of a triangle, 48 B, leaf order: vertex 0 and the two
 // edges Moeller-Trumbore needs.  v0.w carries the scene-order object id.
@@ -148,7 +219,10 @@ struct BvhBuildResult {
   uint32_t n_nodes = 0;
   uint32_t* order = nullptr;     // malloc'ed, n_tris entries: leaf slot -> scene-order triangle
   uint32_t max_depth = 0;        // inner nodes on the longest root-to-leaf chain
+  BvhGrid grid = {};
 };
+// The grid for a scene whose triangles span [mn, mx] (any finite box; an empty one gives a unit grid).
+BvhGrid make_bvh_grid(const float mn[3], const float mx[3]);
 // tri_pos: [n][3][3] floats.  threads = 0: hardware concurrency.  Returns false on allocation failure.
 bool build_bvh(const float* tri_pos, uint32_t n_tris, uint32_t threads, BvhBuildResult* out);
 void free_bvh(BvhBuildResult* r);
@@ -165,6 +239,7 @@ struct DeviceBvhResult {
   TriShade* d_tri_shade = nullptr;
   uint32_t n_nodes = 0;
   uint32_t max_depth = 0;   // inner nodes on the longest root-to-leaf chain
+  BvhGrid grid = {};
   uint32_t rounds = 0;      // clustering rounds it took
   double seconds = 0.0;     // wall clock, upload of the triangles included
 };

@@ -157,6 +157,7 @@ RRT_DEV uint32_t fast_div(uint32_t x, const FastDiv& f) { return (__umulhi(f.m, 
 struct RenderParams {
   PathArrays a;
   const BvhNode* nodes;
+  BvhGrid grid;
   const TriIsect* tris;
   const TriShade* tri_shade;
   const DeviceMaterial* materials;
@@ -524,7 +525,7 @@ __global__ void __launch_bounds__(kTraceBlock, RRT_EXTEND_WAVES) k_extend(Render
   const uint32_t blocks_c = queue_blocks(longest_c, grab);
   TraceCounters ctr = {0, 0, 0};
   ExtendJob<COUNT> job = {p, sc, lens_c, lens_s, blocks_c, grab, parity, nullptr, 0, 0, false, 0, false, false};
-  trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
+  trace_stream<false, COUNT>(p.nodes, p.grid, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
                              blocks_c + queue_blocks(longest_s, grab), RRT_REFILL_QUORUM, job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, 1, ctr);
 }
@@ -623,7 +624,7 @@ __global__ void __launch_bounds__(kTraceBlock, RRT_PRIMARY_WAVES) k_primary(Rend
   const uint32_t grab = grab_size((p.n_slots + kSegments - 1) / kSegments, gridDim.x * (kTraceBlock / 64));
   TraceCounters ctr = {0, 0, 0};
   PrimaryJob<COUNT> job = {p, cam, sc, grab, p.single != 0, 0, 0, 0, 0, 0, false};
-  trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
+  trace_stream<false, COUNT>(p.nodes, p.grid, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
                              (p.n_slots + grab - 1) / grab, RRT_REFILL_QUORUM_COHERENT, job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, 0, ctr);
 }
@@ -897,7 +898,7 @@ __global__ void RRT_TRACE_BOUNDS k_connect(RenderParams p) {
   const uint32_t grab = grab_size(longest, gridDim.x * (kTraceBlock / 64));
   TraceCounters ctr = {0, 0, 0};
   ConnectJob job = {p, sc, lens, grab, nullptr, 0, 0, 0, -1, -1, 0.0f, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
-  trace_stream<true, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkConnect, 0),
+  trace_stream<true, COUNT>(p.nodes, p.grid, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkConnect, 0),
                             queue_blocks(longest, grab), RRT_REFILL_QUORUM, job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, 2, ctr);
 }
@@ -1105,7 +1106,7 @@ __global__ void RRT_TAIL_BOUNDS k_tail(RenderParams p, uint32_t parity) {
   const uint32_t grab = 64;
   TraceCounters ctr = {0, 0, 0};
   TailJob<COUNT> job = {p, sc, lens, grab, parity};
-  trace_stream<false, COUNT>(p.nodes, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
+  trace_stream<false, COUNT>(p.nodes, p.grid, p.tris, sc->n_tris > 0, counter_at(p.a.counters, kRowWorkExtend, 0),
                              queue_blocks(longest, grab), RRT_TAIL_QUORUM, job, &ctr, rrt_trace_stack);
   flush_counters<COUNT>(p.stats, 1, ctr);
 }
@@ -1249,7 +1250,7 @@ struct IntersectJob {
   RRT_DEV void flush(bool, uint32_t) {}
 };
 
-__global__ void RRT_TRACE_BOUNDS k_intersect(const BvhNode* nodes, const TriIsect* tris, const float* __restrict__ tri_pos,
+__global__ void RRT_TRACE_BOUNDS k_intersect(const BvhNode* nodes, BvhGrid grid, const TriIsect* tris, const float* __restrict__ tri_pos,
                                              const ShapesF64* __restrict__ exact, const SceneTables* sc,
                                              const float* __restrict__ org_dir, uint32_t n, int32_t* prim_id, float* t_out,
                                              uint32_t* work_cursor) {
@@ -1258,7 +1259,7 @@ __global__ void RRT_TRACE_BOUNDS k_intersect(const BvhNode* nodes, const TriIsec
   sc = shapes_to_lds(sc, rrt_shape_words);
   TraceCounters ctr = {0, 0, 0};
   IntersectJob job = {tris, tri_pos, exact, sc, org_dir, prim_id, t_out, n, 0, 0};
-  trace_stream<false, false>(nodes, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, RRT_REFILL_QUORUM, job, &ctr,
+  trace_stream<false, false>(nodes, grid, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, RRT_REFILL_QUORUM, job, &ctr,
                              rrt_trace_stack);
 }
 
@@ -1299,7 +1300,7 @@ struct OccludedJob {
   RRT_DEV void flush(bool, uint32_t) {}
 };
 
-__global__ void RRT_TRACE_BOUNDS k_occluded(const BvhNode* nodes, const TriIsect* tris,
+__global__ void RRT_TRACE_BOUNDS k_occluded(const BvhNode* nodes, BvhGrid grid, const TriIsect* tris,
                                                           const SceneTables* sc, const float* __restrict__ odt,
                                                           uint32_t n, uint8_t* out, uint32_t* work_cursor) {
   RRT_DECLARE_TRACE_STACK();
@@ -1307,7 +1308,7 @@ __global__ void RRT_TRACE_BOUNDS k_occluded(const BvhNode* nodes, const TriIsect
   sc = shapes_to_lds(sc, rrt_shape_words);
   TraceCounters ctr = {0, 0, 0};
   OccludedJob job = {sc, odt, out, n, 0, 0, 0.0f};
-  trace_stream<true, false>(nodes, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, RRT_REFILL_QUORUM, job, &ctr,
+  trace_stream<true, false>(nodes, grid, tris, sc->n_tris > 0, work_cursor, (n + 255u) / 256u, RRT_REFILL_QUORUM, job, &ctr,
                             rrt_trace_stack);
 }
 

@@ -57,7 +57,7 @@ typedef volatile __attribute__((address_space(3))) unsigned long long* LdsStackW
   } while (0)
 
 struct RayPre {
-  V3 o, d, inv, ood;  // ood = o * inv
+  V3 o, d, inv;  // inv: 1 / d, of a tiny number with d's sign where d is zero
 };
 
 RRT_DEV RayPre prepare_ray(V3 o, V3 d) {
@@ -71,7 +71,6 @@ RRT_DEV RayPre prepare_ray(V3 o, V3 d) {
   const float dz = fabsf(d.z) > eps ? d.z : copysignf(eps, d.z);
   // hardware reciprocals (1 ulp): the slab test below has more slack than that
   r.inv = mk(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
-  r.ood = o * r.inv;
   return r;
 }
 
@@ -99,16 +98,16 @@ RRT_DEV TriRec load_tri(const TriIsect* __restrict__ tris, int index) {
   t.e2 = rec[2];
   return t;
 }
-RRT_DEV bool intersect_tri(const TriRec& rec, const RayPre& r, float tmin, float tmax, float* t_out, float* u_out,
+RRT_DEV bool intersect_tri(const TriRec& rec, V3 o, V3 d, float tmin, float tmax, float* t_out, float* u_out,
                            float* v_out) {
   const V3 v0 = mk(rec.v0), e1 = mk(rec.e1), e2 = mk(rec.e2);
-  const V3 pvec = cross(r.d, e2);
+  const V3 pvec = cross(d, e2);
   const float det = dot(e1, pvec);
   const float inv_det = __builtin_amdgcn_rcpf(det);  // 1 ulp; a full division is ten instructions per triangle
-  const V3 tvec = r.o - v0;
+  const V3 tvec = o - v0;
   const float u = dot(tvec, pvec) * inv_det;
   const V3 qvec = cross(tvec, e1);
-  const float v = dot(r.d, qvec) * inv_det;
+  const float v = dot(d, qvec) * inv_det;
   const float t = dot(e2, qvec) * inv_det;
   *t_out = t;
   *u_out = u;
@@ -208,32 +207,36 @@ struct Ray {
     tb = tt_;                                       \
     cb = cc_;                                       \
   } while (0)
-// The node's four 16-byte words: {origin, exponents}, children, {lo x, lo y, lo z, hi x}, {hi y, hi z}.
-#define RRT_NODE_LOAD(np, w0, w1, w2, w3)                                                \
+// The node's three 16-byte words: children, {lo x, lo y, lo z, hi x}, {hi y, hi z, corner x | corner y << 16,
+// corner z | shifts << 16}.
+#define RRT_NODE_LOAD(np, w0, w1, w2)                                                    \
   do {                                                                                   \
-    w0 = (np)[0]; w1 = (np)[1]; w2 = (np)[2]; w3 = (np)[3];                              \
+    w0 = (np)[0]; w1 = (np)[1]; w2 = (np)[2];                                            \
   } while (0)
-// Distance along the ray to plane q of an axis: (origin + q * step - o) / d = q * (step / d) + (origin - o) / d.
+// Distance along the ray to plane q of an axis, with c the node's corner and s its shift, both in steps of the
+// scene's grid: (base + (c + q * 2^s) * step - o) / d = q * 2^s * (step / d) + c * (step / d) + (base - o) / d.
+// The ray carries ka = step / d and kb = (base - o) / d; a node costs a = 2^s * ka and b = c * ka + kb per axis.
 #define RRT_Q(w, i) ((float)(((w) >> (8 * (i))) & 0xffu))
+#define RRT_SHIFT(w, k) (((int)((w) << (11 - 5 * (k)))) >> 27)
 #define RRT_CHILD_T(i)                                                                   \
   child_entry(fmaf(RRT_Q(nx_, i), ax, bx), fmaf(RRT_Q(ny_, i), ay, by), fmaf(RRT_Q(nz_, i), az, bz), \
               fmaf(RRT_Q(fx_, i), ax, bx), fmaf(RRT_Q(fy_, i), ay, by), fmaf(RRT_Q(fz_, i), az, bz), tmin, tmax)
-#define RRT_NODE_STEP(w0, w1, w2, w3)                                                    \
+#define RRT_NODE_STEP(w0, w1, w2)                                                        \
   do {                                                                                   \
     RRT_DBG_STEP();                                                                      \
     if (COUNT) ctr->nodes++;                                                             \
-    const float ax = __uint_as_float((w0.w & 0xffu) << 23) * r.inv.x;                    \
-    const float ay = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * r.inv.y;             \
-    const float az = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * r.inv.z;            \
-    const float bx = fmaf(__uint_as_float(w0.x), r.inv.x, -r.ood.x);                     \
-    const float by = fmaf(__uint_as_float(w0.y), r.inv.y, -r.ood.y);                     \
-    const float bz = fmaf(__uint_as_float(w0.z), r.inv.z, -r.ood.z);                     \
+    const float ax = ldexpf(ka.x, RRT_SHIFT(w2.w, 0));                                   \
+    const float ay = ldexpf(ka.y, RRT_SHIFT(w2.w, 1));                                   \
+    const float az = ldexpf(ka.z, RRT_SHIFT(w2.w, 2));                                   \
+    const float bx = fmaf((float)(w2.z & 0xffffu), ka.x, kb.x);                          \
+    const float by = fmaf((float)(w2.z >> 16), ka.y, kb.y);                              \
+    const float bz = fmaf((float)(w2.w & 0xffffu), ka.z, kb.z);                          \
     /* per axis the ray meets the minimum plane first if it runs upwards, else the maximum plane */ \
-    const bool ux_ = r.inv.x >= 0.0f, uy_ = r.inv.y >= 0.0f, uz_ = r.inv.z >= 0.0f;      \
-    const uint32_t nx_ = ux_ ? w2.x : w2.w, fx_ = ux_ ? w2.w : w2.x;                     \
-    const uint32_t ny_ = uy_ ? w2.y : w3.x, fy_ = uy_ ? w3.x : w2.y;                     \
-    const uint32_t nz_ = uz_ ? w2.z : w3.y, fz_ = uz_ ? w3.y : w2.z;                     \
-    int c0 = (int)w1.x, c1 = (int)w1.y, c2 = (int)w1.z, c3 = (int)w1.w;                  \
+    const bool ux_ = ka.x >= 0.0f, uy_ = ka.y >= 0.0f, uz_ = ka.z >= 0.0f;               \
+    const uint32_t nx_ = ux_ ? w1.x : w1.w, fx_ = ux_ ? w1.w : w1.x;                     \
+    const uint32_t ny_ = uy_ ? w1.y : w2.x, fy_ = uy_ ? w2.x : w1.y;                     \
+    const uint32_t nz_ = uz_ ? w1.z : w2.y, fz_ = uz_ ? w2.y : w1.z;                     \
+    int c0 = (int)w0.x, c1 = (int)w0.y, c2 = (int)w0.z, c3 = (int)w0.w;                  \
     float t0 = RRT_CHILD_T(0);                                                           \
     float t1 = RRT_CHILD_T(1);                                                           \
     float t2 = RRT_CHILD_T(2);                                                           \
@@ -255,8 +258,8 @@ struct Ray {
   } while (0)
 
 template <bool ANY, bool COUNT, class Job>
-RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __restrict__ tris, bool has_tris,
-                          uint32_t* work_cursor, uint32_t n_blocks, int refill_quorum, Job& job, TraceCounters* ctr,
+RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const BvhGrid& grid, const TriIsect* __restrict__ tris,
+                          bool has_tris, uint32_t* work_cursor, uint32_t n_blocks, int refill_quorum, Job& job, TraceCounters* ctr,
                           int2* lds_stack) {
   enum { kIdle = 0, kTravelling = 1, kArrived = 2, kJobDone = 3 };
   // this thread's column: entry e at lds[e * kTraceBlock]
@@ -270,8 +273,10 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
   bool exhausted = false;                   // wave-uniform: the global cursor has run past `total`
   int state = kIdle;
   uint32_t my_block = 0;
-  RayPre r;
-  r.o = r.d = r.inv = r.ood = mk(0.0f, 0.0f, 0.0f);
+  // the ray: origin, direction, and the two vectors a node step needs (see RRT_CHILD_T)
+  V3 ro = mk(0.0f, 0.0f, 0.0f), rd = ro, ka = ro, kb = ro;
+  const V3 g_base = mk(grid.base[0], grid.base[1], grid.base[2]), g_step = mk(grid.step[0], grid.step[1], grid.step[2]),
+           g_inv_step = mk(grid.inv_step[0], grid.inv_step[1], grid.inv_step[2]);
   float tmin = 0.0f, tmax = 0.0f;
   int skip = -1, cur = 0, sp = 0;
   Hit hit;
@@ -279,15 +284,16 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
   hit.t = INFINITY;
   hit.u = hit.v = 0.0f;
   bool found = false;
-  // The root's grid spans every triangle: origin + [0, 255] steps per axis, padded so that a ray any
-  // child-box test below would let in (those round by a few ulps) is let in here as well.
+  // The root's grid spans every triangle: corner + [0, 255] node steps per axis, here in steps of the scene's
+  // grid and padded so that a ray any child-box test below would let in (those round by a few ulps) is let in
+  // here as well.
   float root_lo[3] = {0.0f, 0.0f, 0.0f}, root_hi[3] = {0.0f, 0.0f, 0.0f};
   if (RRT_ROOT_TEST && Job::kRootTest && has_tris) {
     for (int k = 0; k < 3; ++k) {
-      const float extent = 255.0f * __uint_as_float((uint32_t)nodes[0].exp[k] << 23);
+      const float extent = ldexpf(255.0f, node_shift(nodes[0], k));
       const float pad = 1e-4f * extent + 1e-30f;
-      root_lo[k] = nodes[0].origin[k] - pad;
-      root_hi[k] = nodes[0].origin[k] + extent + pad;
+      root_lo[k] = (float)nodes[0].corner[k] - pad;
+      root_hi[k] = (float)nodes[0].corner[k] + extent + pad;
     }
   }
 #ifdef RRT_PHASE_CLOCKS
@@ -315,7 +321,13 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
 #define RRT_START_RAY(ray)                                   \
   do {                                                       \
     RRT_DBG_RAY_BEGIN();                                     \
-    r = prepare_ray((ray).o, (ray).d);                       \
+    {                                                        \
+      const RayPre pre_ = prepare_ray((ray).o, (ray).d);     \
+      ro = pre_.o;                                           \
+      rd = pre_.d;                                           \
+      ka = pre_.inv * g_step;                                \
+      kb = (g_base - pre_.o) * pre_.inv;                     \
+    }                                                        \
     tmin = (ray).tmin;                                       \
     tmax = (ray).tmax;                                       \
     skip = (ray).skip;                                       \
@@ -326,9 +338,9 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
     cur = 0;                                                 \
     bool enter_ = has_tris;                                  \
     if (RRT_ROOT_TEST && Job::kRootTest && has_tris) {       \
-      const float ax_ = fmaf(root_lo[0], r.inv.x, -r.ood.x), bx_ = fmaf(root_hi[0], r.inv.x, -r.ood.x); \
-      const float ay_ = fmaf(root_lo[1], r.inv.y, -r.ood.y), by_ = fmaf(root_hi[1], r.inv.y, -r.ood.y); \
-      const float az_ = fmaf(root_lo[2], r.inv.z, -r.ood.z), bz_ = fmaf(root_hi[2], r.inv.z, -r.ood.z); \
+      const float ax_ = fmaf(root_lo[0], ka.x, kb.x), bx_ = fmaf(root_hi[0], ka.x, kb.x); \
+      const float ay_ = fmaf(root_lo[1], ka.y, kb.y), by_ = fmaf(root_hi[1], ka.y, kb.y); \
+      const float az_ = fmaf(root_lo[2], ka.z, kb.z), bz_ = fmaf(root_hi[2], ka.z, kb.z); \
       const float tn_ = fmaxf(fmaxf(fminf(ax_, bx_), fminf(ay_, by_)), fmaxf(fminf(az_, bz_), tmin));   \
       const float tf_ = fminf(fminf(fmaxf(ax_, bx_), fmaxf(ay_, by_)), fminf(fmaxf(az_, bz_), tmax));   \
       enter_ = tn_ <= tf_ * 1.0000005f;                      \
@@ -358,6 +370,10 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
     if (state == kArrived) {
       RRT_DBG_RAY_END();
       Ray ray;
+      RayPre r;  // ka = inv * step with step a power of two: the product below is inv again, to the bit
+      r.o = ro;
+      r.d = rd;
+      r.inv = ka * g_inv_step;
       if (job.advance(found, hit, r, &ray)) RRT_START_RAY(ray);
       else state = kJobDone;
     }
@@ -447,14 +463,14 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
       for (;;) {
         const bool at_node = state == kTravelling && cur >= 0;
         const bool at_leaf = state == kTravelling && cur < 0;
-        uint4 w0, w1, w2, w3;
+        uint4 w0, w1, w2;
         TriRec rec;
         int ti = 0;
-        w0 = w1 = w2 = w3 = make_uint4(0u, 0u, 0u, 0u);
+        w0 = w1 = w2 = make_uint4(0u, 0u, 0u, 0u);
         rec.v0 = rec.e1 = rec.e2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (at_node) {
           const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
-          RRT_NODE_LOAD(np, w0, w1, w2, w3);
+          RRT_NODE_LOAD(np, w0, w1, w2);
         }
         if (at_leaf) {
           ti = (~cur) >> 2;  // leaf: ~cur = first << 2 | (count - 1)
@@ -465,12 +481,12 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
         asm volatile("" ::: "memory");
         RRT_DBG_ADD(3, 1);
         if (at_node) {
-          RRT_NODE_STEP(w0, w1, w2, w3);
+          RRT_NODE_STEP(w0, w1, w2);
         }
         if (at_leaf) {
           if (COUNT) ctr->tris++;
           float t, u, v;
-          if (intersect_tri(rec, r, tmin, tmax, &t, &u, &v) && ti != skip) {
+          if (intersect_tri(rec, ro, rd, tmin, tmax, &t, &u, &v) && ti != skip) {
             found = true;
             tmax = t;
             hit.prim = ti;
@@ -498,9 +514,9 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
 #endif
           if (state == kTravelling && cur >= 0) {
             const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
-            uint4 w0, w1, w2, w3;
-            RRT_NODE_LOAD(np, w0, w1, w2, w3);
-            RRT_NODE_STEP(w0, w1, w2, w3);
+            uint4 w0, w1, w2;
+            RRT_NODE_LOAD(np, w0, w1, w2);
+            RRT_NODE_STEP(w0, w1, w2);
           }
           const unsigned long long inner = __ballot(state == kTravelling && cur >= 0);
           const unsigned long long at_leaf = __ballot(state == kTravelling && cur < 0);
@@ -520,7 +536,7 @@ RRT_DEV void trace_stream(const BvhNode* __restrict__ nodes, const TriIsect* __r
   do {                                                                                 \
     if (COUNT) ctr->tris++;                                                            \
     float t_, u_, v_;                                                                  \
-    if (intersect_tri(record, r, tmin, tmax, &t_, &u_, &v_) && (index) != skip) {      \
+    if (intersect_tri(record, ro, rd, tmin, tmax, &t_, &u_, &v_) && (index) != skip) {      \
       found = true;                                                                    \
       tmax = t_;                                                                       \
       hit.prim = (index);                                                              \

@@ -263,6 +263,42 @@ def test_stress_scene(rrt, oracle_binding, gpu_ctx, parity_record, builder):
     assert close.mean() >= 0.998
 
 
+@pytest.mark.parametrize("builder", [0, 1], indirect=True)
+def test_first_hit_far_from_the_origin(rrt, oracle_binding, gpu_ctx, parity_record, builder):
+    """A scene thousands of units from the origin with a wide range of sizes: 60 k triangles of 0.05 units in a
+    cluster 20 units across, inside 2 k triangles of 100 units spread over 3000 units.  The node corners lie on a
+    16-bit grid of the whole scene (a step of 0.06 units here, larger than the small triangles) and the ray's
+    distances to the grid are differences of large numbers: ids must still be the oracle's, distances within 1e-5,
+    and the hierarchy of either builder must pass the invariant check."""
+    rng = np.random.default_rng(21)
+    shift = np.array([4000.0, -2500.0, 7000.0])
+    small = rng.uniform(-10, 10, size=(60000, 1, 3)) + rng.normal(scale=0.05, size=(60000, 3, 3))
+    large = rng.uniform(-1500, 1500, size=(2000, 1, 3)) + rng.normal(scale=100.0, size=(2000, 3, 3))
+    pos = (np.concatenate([small, large]) + shift).astype(np.float32)
+    n = len(pos)
+    nrm = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]).astype(np.float64)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+    scene = rrt.SceneArrays(pos, np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32), np.zeros(n),
+                            materials=[rrt.make_material(rrt.MAT_MATTE, kd=(0.5, 0.5, 0.5))])
+    gpu_ctx.upload_scene(scene)
+    bad, nodes, depth, on_device, _ = gpu_ctx.bvh_check(pos.reshape(-1, 9))
+    assert bad == 0 and on_device == bool(builder)
+    # half of the rays start inside the small cluster and aim at it, half cross the large one
+    o_in = rng.uniform(-12, 12, size=(3000, 3))
+    d_in = rng.uniform(-10, 10, size=(3000, 3)) - o_in
+    o_out = rng.uniform(-1600, 1600, size=(3000, 3))
+    d_out = rng.normal(size=(3000, 3))
+    org = np.concatenate([o_in, o_out]) + shift
+    d = np.concatenate([d_in, d_out])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], axis=1).astype(np.float32).astype(np.float64)
+    orc = oracle_binding.Oracle(scene.desc())
+    ref_prim, ref_t, margin = orc.intersect(rays, with_margin=True)
+    assert (ref_prim[:3000] >= 0).sum() > 300 and (ref_prim[3000:] >= 0).sum() > 300
+    _check_first_hit(gpu_ctx, rays, ref_prim, ref_t, margin, parity_record,
+                     "first_hit_far_from_origin" + ("_device_bvh" if builder else ""), min_clear=0.9)
+
+
 def _device_film(rrt, ctx, scene, rs, w, h, spp, depth, seed, crop=None):
     cam = rrt.Camera.from_settings(rs, w, h)
     s = rrt.make_settings(w, h, depth, rs.clamp, seed=seed, crop=crop)

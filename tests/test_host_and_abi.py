@@ -71,7 +71,8 @@ def test_hierarchy_invariants(rrt):
     """The 4-wide hierarchy with 8-bit quantised child boxes, built on the host as rrt_upload_scene
     builds it: every triangle inside the decoded box of every node above it, each in exactly one leaf.
     Random soup, a regular grid (planes exactly on grid steps: boxes with zero padding), flat and
-    degenerate triangles, huge and tiny coordinates side by side, 0 / 1 / 5 triangles."""
+    degenerate triangles, huge and tiny coordinates side by side, a scene far from the origin whose small
+    triangles are smaller than a step of the scene-wide grid the node corners lie on, 0 / 1 / 5 triangles."""
     rng = np.random.default_rng(5)
     soup = rng.uniform(-1, 1, (20000, 1, 3)) * 50 + rng.normal(0, 0.3, (20000, 3, 3))
     g = np.stack(np.meshgrid(np.arange(40.0), np.arange(40.0), indexing="ij"), axis=-1).reshape(-1, 2)
@@ -79,7 +80,8 @@ def test_hierarchy_invariants(rrt):
     grid[:, 0, :2], grid[:, 1, :2], grid[:, 2, :2] = g, g + [1, 0], g + [0, 1]   # all in the plane z = 0
     mixed = np.concatenate([soup[:3000] * 1e-4 + 1000.0, soup[:3000] * 1e3, np.zeros((10, 3, 3)),
                             np.tile(soup[:1], (20, 1, 1))])                       # duplicates and points
-    for name, tris in (("soup", soup), ("grid", grid), ("mixed", mixed), ("one", soup[:1]), ("five", soup[:5]),
+    far = np.concatenate([soup[:5000] * 0.01, soup[:500] * 30.0]) + [4000.0, -2500.0, 7000.0]   # small inside large, off-centre
+    for name, tris in (("soup", soup), ("grid", grid), ("mixed", mixed), ("far", far), ("one", soup[:1]), ("five", soup[:5]),
                        ("none", soup[:0])):
         bad, n_nodes, depth = rrt.bvh_selfcheck(tris)
         assert bad == 0, (name, bad)
