@@ -411,9 +411,13 @@ __global__ void __launch_bounds__(kBuildBlock) k_records(const float* __restrict
   t.e2 = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.0f);
   tris[slot] = t;
   TriShade s;
-  s.n0 = make_float4(q[0], q[1], q[2], __uint_as_float(mat[id]));
+  s.v0 = make_float4(p[0], p[1], p[2], __uint_as_float(mat[id]));
+  s.e1 = t.e1;
+  s.e2 = t.e2;
+  s.n0 = make_float4(q[0], q[1], q[2], 0.0f);
   s.n1 = make_float4(q[3], q[4], q[5], 0.0f);
   s.n2 = make_float4(q[6], q[7], q[8], 0.0f);
+  s.unused[0] = s.unused[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   shade[slot] = s;
 }
 

@@ -754,9 +754,9 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
     ~BvhOwner() { free_bvh(b); }
   } bvh_owner{&bvh};
   if (!device_build && !build_bvh(sd->tri_pos, sd->n_tris, 0, &bvh)) { free_scene(ctx); return fail(ctx, RRT_E_NOMEM, "BVH build: out of host memory"); }
-  // (malloc'ed, not vectors: 100 bytes per triangle that need no zeroing first)
+  // (malloc'ed, not vectors: 176 bytes per triangle that need no zeroing first)
   TriIsect* tris = device_build ? nullptr : (TriIsect*)std::malloc(sizeof(TriIsect) * std::max<size_t>(sd->n_tris, 1));
-  TriShade* shade = device_build ? nullptr : (TriShade*)std::malloc(sizeof(TriShade) * std::max<size_t>(sd->n_tris, 1));
+  TriShade* shade = device_build ? nullptr : (TriShade*)std::aligned_alloc(alignof(TriShade), sizeof(TriShade) * std::max<size_t>(sd->n_tris, 1));
   struct HostRecords {
     TriIsect* a; TriShade* b;
     ~HostRecords() { std::free(a); std::free(b); }
@@ -779,9 +779,14 @@ int upload_scene_impl(rrt_ctx* ctx, const rrt_scene_desc* sd) {
     bits = sd->tri_mat[id];
     float matf;
     std::memcpy(&matf, &bits, 4);
-    shade[slot].n0 = float4{n[0], n[1], n[2], matf};
-    shade[slot].n1 = float4{n[3], n[4], n[5], 0.0f};
-    shade[slot].n2 = float4{n[6], n[7], n[8], 0.0f};
+    TriShade& s = shade[slot];
+    s.v0 = float4{p[0], p[1], p[2], matf};
+    s.e1 = t.e1;
+    s.e2 = t.e2;
+    s.n0 = float4{n[0], n[1], n[2], 0.0f};
+    s.n1 = float4{n[3], n[4], n[5], 0.0f};
+    s.n2 = float4{n[6], n[7], n[8], 0.0f};
+    s.unused[0] = s.unused[1] = float4{0.0f, 0.0f, 0.0f, 0.0f};
   });
 
   // ---- small tables

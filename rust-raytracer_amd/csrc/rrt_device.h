@@ -123,11 +123,17 @@ struct TriIsect {
   float4 e2;  // xyz = p2 - p0
 };
 
-// Shading record of a triangle, 48 B, leaf order: the three vertex normals
-// (objects/triangle.rs:84-107).  n0.w carries the material index bits.
-struct TriShade {
+// Shading record of a triangle, one 128-byte line, leaf order: all that the surface interaction of a
+// hit needs -- vertex 0 and the edges once more, the three vertex normals (objects/triangle.rs:84-107),
+// the material -- so that a shaded bounce fetches one line for its triangle instead of parts of three
+// or four (the shading kernel runs at the rate at which the chip fetches scattered lines).
+// v0.w carries the material index bits.
+struct alignas(128) TriShade {
+  float4 v0, e1, e2;  // as in TriIsect
   float4 n0, n1, n2;
+  float4 unused[2];
 };
+static_assert(sizeof(TriShade) == 128, "TriShade must be one cache line");
 
 enum DiffuseKind : int { DIFF_NONE = 0, DIFF_LAMBERT = 1, DIFF_OREN_NAYAR = 2 };
 enum SpecKind : int { SPEC_NONE = 0, SPEC_MIRROR_DIELECTRIC = 1, SPEC_MICROFACET = 2, SPEC_MIRROR_NOOP = 3 };

@@ -679,7 +679,7 @@ RRT_DEV ShadeOut shade_bounce(const RenderParams& p, const SceneTables* sc, cons
       float pdf_s;
       bsdf_eval(s, m, ls.wi, &f, &pdf_s);
       f = f * fabsf(dot(ls.wi, s.ns));
-      if (!is_zero(f) && !(prim < sc->n_tris && own_triangle_occludes(p.tris, prim, s, ls.wi))) {
+      if (!is_zero(f) && !(prim < sc->n_tris && own_triangle_occludes(p.tri_shade, prim, s, ls.wi))) {
         const float w = ls.delta ? 1.0f : power_heuristic(ls.pdf, pdf_s);
         o.light_c = beta * f * ls.li * (w * n_lights / ls.pdf);
         // check_light_visible (src/renderer.rs:277-295): from the surface point towards the
@@ -767,7 +767,7 @@ __global__ void RRT_SHADE_BOUNDS k_shade(RenderParams p, uint32_t parity) {
     else p.a.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int prim = __float_as_int(h4.x);
     // AreaLight::emitting is zero (lights/area.rs:23-25): hitting an emitter adds nothing
-    const Surface s = prim < sc->n_tris ? surface_triangle(p.tris, p.tri_shade, prim, h4.z, h4.w, dir)
+    const Surface s = prim < sc->n_tris ? surface_triangle(p.tri_shade, prim, h4.z, h4.w, dir)
                                         : surface_other(sc, prim, h4.y, mk(p.a.trace[slot].ray_o), dir);
     const ShadeOut o = shade_bounce(p, sc, s, prim, y * p.width + x, sample, bounce, beta);
     has_light = (o.flags & kHasLightRay) != 0;
@@ -1032,7 +1032,7 @@ struct TailJob {
     }
     uint32_t x, y, k;
     slot_pixel(p, slot, &x, &y, &k);
-    const Surface s = h.prim < sc->n_tris ? surface_triangle(p.tris, p.tri_shade, h.prim, h.u, h.v, r.d)
+    const Surface s = h.prim < sc->n_tris ? surface_triangle(p.tri_shade, h.prim, h.u, h.v, r.d)
                                           : surface_other(sc, h.prim, h.t, r.o, r.d);
     const ShadeOut o = shade_bounce(p, sc, s, h.prim, y * p.width + x, p.sample_begin + k, state >> 1, beta);
     ++n_bounces;

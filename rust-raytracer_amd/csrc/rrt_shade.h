@@ -26,17 +26,15 @@ struct Surface {
 
 // ---------------------------------------------------------------- surface interaction
 // Triangle::test_intersect after the hit test (objects/triangle.rs:183-256).
-RRT_DEV Surface surface_triangle(const TriIsect* __restrict__ tris, const TriShade* __restrict__ shade, int prim, float u,
-                                 float v, V3 dir) {
-  const float4* ti = reinterpret_cast<const float4*>(tris + prim);
+RRT_DEV Surface surface_triangle(const TriShade* __restrict__ shade, int prim, float u, float v, V3 dir) {
   const float4* ts4 = reinterpret_cast<const float4*>(shade + prim);
-  const float4 a = ti[0], b = ti[1], c = ti[2];
-  const float4 na = ts4[0], nb = ts4[1], nc = ts4[2];
+  const float4 a = ts4[0], b = ts4[1], c = ts4[2];
+  const float4 na = ts4[3], nb = ts4[4], nc = ts4[5];
   const V3 p0 = mk(a), e1 = mk(b), e2 = mk(c);
   const V3 n0 = mk(na), n1 = mk(nb), n2 = mk(nc);
   const float b0 = 1.0f - u - v, b1 = u, b2 = v;
   Surface s;
-  s.material = __float_as_int(na.w);
+  s.material = __float_as_int(a.w);
   s.light = -1;
   s.wo = -dir;
   s.ns = normalize(b0 * n0 + b1 * n1 + b2 * n2);
@@ -75,10 +73,10 @@ RRT_DEV Surface surface_triangle(const TriIsect* __restrict__ tris, const TriSha
 // plane would hit it at random), so the crossing is decided here, from the lift itself.
 // A lift below 1e-5 of the triangle's size is taken for zero: on a flat-shaded face the exact lift
 // is 0, f64 computes ~1e-17 (less than the ray's 1e-9 head start, so no hit), f32 computes ~1e-7.
-RRT_DEV bool own_triangle_occludes(const TriIsect* __restrict__ tris, int prim, const Surface& s, V3 wi) {
+RRT_DEV bool own_triangle_occludes(const TriShade* __restrict__ shade, int prim, const Surface& s, V3 wi) {
   const float c = dot(wi, s.ng);
   if (s.lift == 0.0f || c * s.lift >= 0.0f) return false;
-  const float4* ti = reinterpret_cast<const float4*>(tris + prim);
+  const float4* ti = reinterpret_cast<const float4*>(shade + prim);
   const V3 p0 = mk(ti[0]), e1 = mk(ti[1]), e2 = mk(ti[2]);
   if (s.lift * s.lift <= 1e-10f * fmaxf(norm2(e1), norm2(e2))) return false;
   const V3 x = s.p + wi * (-s.lift / c);
