@@ -90,6 +90,22 @@ def test_hierarchy_invariants(rrt):
             assert n_nodes < len(tris) and depth < 64, (name, n_nodes, depth)
 
 
+@pytest.mark.parametrize("scale", [1e-12, 1e-6, 1.0, 1e6, 1e12])
+@pytest.mark.parametrize("offset", [0.0, 1.0, -3e3])
+def test_hierarchy_invariants_over_scales(rrt, scale, offset):
+    """The node corners lie on a 16-bit power-of-two grid of the whole scene and the child boxes on 8-bit
+    grids below it: whatever the size of the scene and wherever it lies (offsets are in units of its size,
+    so the largest puts it thousands of its own extents from the origin, where neighbouring f32
+    coordinates are a few grid steps apart), every triangle must lie inside every decoded box above it."""
+    rng = np.random.default_rng(17)
+    tris = rng.uniform(-1, 1, (4000, 1, 3)) + rng.normal(0, 0.02, (4000, 3, 3))
+    tris[:200] = rng.uniform(-1, 1, (200, 1, 3)) + rng.normal(0, 1e-5, (200, 3, 3))   # slivers far below a grid step
+    tris = ((tris + offset) * scale).astype(np.float32)
+    bad, n_nodes, depth = rrt.bvh_selfcheck(tris)
+    assert bad == 0, (scale, offset, bad)
+    assert 1 <= n_nodes < len(tris) and depth < 64
+
+
 def _read_png(path):
     """Decodes an 8-bit RGB, filter-0 PNG with the standard library (checks every chunk's CRC)."""
     import struct
