@@ -47,6 +47,9 @@ stress = _load("rust_raytracer_amd.stress", "rust-raytracer_amd/stress.py")
 rrbuild = _load("rust_raytracer_amd.build", "rust-raytracer_amd/build.py")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+# The rate at which one MI355X fetches 128-byte lines that lanes pick at random (tools/fetch_probe.hip: 40-44 G lines/s from
+# a 4 GiB table and from one resident in the Infinity Cache alike): what scattered traffic runs against, rather than bytes.
+SCATTERED_LINES_PEAK_G = 42.0
 # algorithmic bytes per ray: 64 B per BVH node visited (two boxes of six f32 and the links, the figure the roofline is
 # defined on), 36 B per triangle tested (nine f32 positions), 32 B ray in, 16 B hit out.  The node as stored is smaller
 # (48 B: four links, four boxes of six bytes, corner and grid shifts); the roofline entry carries the rate on that as well.
@@ -361,11 +364,21 @@ def main():
                         "frac_fetched": e["fetched_gb_per_s"] / HBM_PEAK_GBS,
                         "tris_per_ray": e["tris_per_ray"], "launches": e["launches"], "avg_launch_ms": e["avg_launch_ms"],
                         "rays_per_launch": e["rays_per_launch"]}
+            k = (prof or {}).get("kernels", {}).get("k_extend")
+            if k and k.get("read_lines_per_frame") is not None:
+                # the same traffic as memory-side requests of the L2s (one per 128-byte line read, one per 64 bytes
+                # written) over the launches' own time, against the probe's rate for scattered lines
+                reqs = (k["read_lines_per_frame"] + k["write_requests_per_frame"]) * args.steps / e["launches"]
+                rate = reqs / (e["avg_launch_ms"] * 1e-3) * 1e-9
+                roofline["memory_requests"] = {"per_launch": reqs, "g_per_s": rate, "peak_g_per_s": SCATTERED_LINES_PEAK_G,
+                                               "frac": rate / SCATTERED_LINES_PEAK_G}
             if prof_note:
                 roofline["traffic_source"] = prof_note
             if alone_ms:
                 roofline["avg_launch_ms_alone"] = alone_ms
                 roofline["frac_alone"] = roofline["frac"] * e["avg_launch_ms"] / alone_ms
+                if "memory_requests" in roofline:
+                    roofline["memory_requests"]["frac_alone"] = roofline["memory_requests"]["frac"] * e["avg_launch_ms"] / alone_ms
         if st.ms_shade > 0:
             # shade streams path state: per shaded bounce 2 x (ray 32 + throughput 12 + radiance 12 + pixel / flags 8 +
             # rng 8 + hit 16 + shadow ray 44) = 264 algorithmic bytes
@@ -379,6 +392,11 @@ def main():
                 roofline_shade["traffic"] = k["hbm_bytes_per_frame"]   # per step (one frame), all its launches
                 roofline_shade["hbm_gb_per_s"] = k["hbm_bytes_per_frame"] / (st.ms_shade / args.steps * 1e-3) * 1e-9
                 roofline_shade["l2_hit_rate"] = k.get("l2_hit_rate")
+                if k.get("read_lines_per_frame") is not None:
+                    reqs = k["read_lines_per_frame"] + k["write_requests_per_frame"]
+                    rate = reqs / (st.ms_shade / args.steps * 1e-3) * 1e-9
+                    roofline_shade["memory_requests"] = {"per_step": reqs, "g_per_s": rate, "peak_g_per_s": SCATTERED_LINES_PEAK_G,
+                                                         "frac": rate / SCATTERED_LINES_PEAK_G}
         out = {
             "metric": "camera-path samples/sec",
             "value": value,

@@ -2,7 +2,7 @@
 
     profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
     profiles/<tag>_pmc_summary.json   per-kernel sums of FETCH_SIZE / WRITE_SIZE / TCC_HIT / TCC_MISS
-    profiles/extend_traffic.json      HBM bytes of all k_extend launches of one frame, read by bench.py
+    profiles/extend_traffic.json      HBM bytes and memory-side requests of every kernel over one frame, read by bench.py
 
 FETCH_SIZE and WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes for
 16-byte-per-lane loads (which is what every traversal load is), so it is doubled before use.
@@ -67,8 +67,13 @@ def main(tag):
                 continue
             short = name.replace("rrt::", "").split("<")[0]
             k = per_kernel.setdefault(short, {"hbm_bytes_per_frame": 0.0, "launches_per_frame": 0.0, "us_per_frame": 0.0,
+                                              "read_lines_per_frame": 0.0, "write_requests_per_frame": 0.0,
                                               "_hit": 0.0, "_miss": 0.0})
             k["hbm_bytes_per_frame"] += e["hbm_bytes_per_launch"] * e["launches"] / frames
+            # memory-side requests of the L2s: one per 128-byte line read (FETCH_SIZE tallies it at 64 bytes, for
+            # streams and for scattered 16-byte loads alike: tools/fetch_probe.hip), one per 64 bytes written
+            k["read_lines_per_frame"] += e["counters"]["FETCH_SIZE"] * 1024.0 / 64.0 / frames
+            k["write_requests_per_frame"] += e["counters"]["WRITE_SIZE"] * 1024.0 / 64.0 / frames
             k["launches_per_frame"] += e["launches"] / frames
             k["us_per_frame"] += e["avg_launch_us"] * e["launches"] / frames
             k["_hit"] += e["counters"].get("TCC_HIT_sum", 0.0)
@@ -77,6 +82,8 @@ def main(tag):
             hit, miss = k.pop("_hit"), k.pop("_miss")
             k["l2_hit_rate"] = hit / (hit + miss) if hit + miss > 0 else None
             k["hbm_gb_per_s"] = k["hbm_bytes_per_frame"] / (k["us_per_frame"] * 1e-6) * 1e-9 if k["us_per_frame"] > 0 else None
+            k["requests_g_per_s"] = ((k["read_lines_per_frame"] + k["write_requests_per_frame"]) / (k["us_per_frame"] * 1e-6) * 1e-9
+                                     if k["us_per_frame"] > 0 else None)
         with open(os.path.join(dst, "extend_traffic.json"), "w") as f:
             json.dump({"source": tag, "kernel": "k_extend", "workload": "buddha 1920x1080, 256 spp",
                        "hbm_bytes_per_frame": ext["hbm_bytes_per_launch"] * ext["launches"] / frames,
