@@ -85,7 +85,7 @@ RRT_HD inline void encode_node_boxes(const BvhGrid& g, const float (*mn)[3], con
       all_mx = mx[i][k] > all_mx ? mx[i][k] : all_mx;
     }
     double c = floor(((double)all_mn - (double)g.base[k]) * (double)g.inv_step[k]);
-    c = c < 0.0 ? 0.0 : (c > 65535.0 ? 65535.0 : c);
+    c = c >= 0.0 ? (c > 65535.0 ? 65535.0 : c) : 0.0;  // (a NaN from a vertex that is not a number goes to 0)
     uint32_t corner = (uint32_t)c;
     while (corner > 0 && node_plane(g, corner, 0, k, 0) > (double)all_mn) --corner;
     // the smallest shift whose 255 steps reach the far side
@@ -104,8 +104,8 @@ RRT_HD inline void encode_node_boxes(const BvhGrid& g, const float (*mn)[3], con
     for (int i = 0; i < n; ++i) {
       double lo = floor(((double)mn[i][k] - origin) * inv_node_step);
       double hi = ceil(((double)mx[i][k] - origin) * inv_node_step);
-      lo = lo < 0.0 ? 0.0 : (lo > 255.0 ? 255.0 : lo);
-      hi = hi < 0.0 ? 0.0 : (hi > 255.0 ? 255.0 : hi);
+      lo = lo >= 0.0 ? (lo > 255.0 ? 255.0 : lo) : 0.0;
+      hi = hi >= 0.0 ? (hi > 255.0 ? 255.0 : hi) : 0.0;
       uint32_t qlo = (uint32_t)lo, qhi = (uint32_t)hi;
       while (qlo > 0 && node_plane(g, corner, shift, k, qlo) > (double)mn[i][k]) --qlo;
       while (qhi < 255 && node_plane(g, corner, shift, k, qhi) < (double)mx[i][k]) ++qhi;

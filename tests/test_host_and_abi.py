@@ -106,6 +106,18 @@ def test_hierarchy_invariants_over_scales(rrt, scale, offset):
     assert 1 <= n_nodes < len(tris) and depth < 64
 
 
+def test_hierarchy_build_survives_vertices_that_are_not_numbers(rrt):
+    """A NaN or an infinity among the vertices must not take the builder or its checker down (what such a
+    triangle's boxes are is nobody's concern: it cannot be hit)."""
+    rng = np.random.default_rng(23)
+    tris = (rng.uniform(-1, 1, (500, 1, 3)) + rng.normal(0, 0.05, (500, 3, 3))).astype(np.float32)
+    for value in (np.nan, np.inf, -np.inf):
+        t = tris.copy()
+        t[17, 1, 2] = value
+        bad, n_nodes, depth = rrt.bvh_selfcheck(t)
+        assert n_nodes >= 1 and depth >= 1
+
+
 def _read_png(path):
     """Decodes an 8-bit RGB, filter-0 PNG with the standard library (checks every chunk's CRC)."""
     import struct
